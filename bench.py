@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Headline benchmark: EI candidates scored per second at N = 2048 observations, d = 32 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--candidates M_PER_GPU] [--workload metric|cfg2|cfg3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path for one GP hyper sample over this rank's shard of the candidate grid,
+everything resident in HBM: K(X,X) assembly + blocked Cholesky + L^-1 + alpha (the GP fit, redundantly on
+every rank), K(X*,X) assembly + posterior mean, posterior variance (the M*N^2 fp64-MFMA GEMM), EI, score:div,
+arg-max, and for N > 1 the single (value, index) exchange over RCCL.  Weak scaling: every rank owns
+--candidates rows of one global Sobol grid (rank r generates rows [r*M, (r+1)*M) itself).
+
+Inputs (synthetic, deterministic): candidates = Sobol points 1..M_total in the unit cube (grids/sobol.lua
+semantics, generated on the GPU); observations = the N Sobol points that follow them; Y = the reference's
+objective restated on the host (bot7_amd.benchmarks); hypers lenscale_sq = d/8, amp = var(Y), mean = mean(Y),
+noise = 1e-4*amp.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (d, N, default per-GPU M, objective, score)
+    "metric": (32, 2048, 1 << 20, "ackley", "ei"),
+    "cfg3": (32, 1024, 262144, "ackley", "ei"),
+    "cfg2": (6, 256, 32768, "hartmann6", "cb"),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; measured 74.5-77.3 (profiles/r01_mfma_f64_probe.txt)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
+    ap.add_argument("--candidates", type=int, default=0, help="candidates per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=131072, help="candidates in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(d, N, objective, score, sample, X_obs, Y, hyp):
+    """The oracle (port of the Torch7 CPU path: BLAS dgemm / LAPACK dpotrf / dtrtrs through numpy+scipy) timed on
+    this box's host cores on a bounded sample of the same workload: one fit + `sample` candidates scored."""
+    from oracle import cport, gp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        limiter = None
+    X_hid = cport.sobol(sample, d, 1)
+    t0 = time.perf_counter()
+    f = gp.fit(X_obs, Y, **hyp)
+    t_fit = time.perf_counter() - t0
+    mu, var = gp.predict(f, X_hid)
+    if score == "ei":
+        s = cport.ei(mu, var, [float(Y.min())])
+    else:
+        s = cport.cb(mu, var)
+    idx, _ = cport.argmax_first(s)
+    t = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+    return {"value": sample / t, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "1 GP fit (N=%d, %.3f s) + %d Sobol candidates scored with %s in %.2f s "
+                      "(numpy/scipy OpenBLAS+LAPACK restatement of the Torch7 CPU path; not Torch7 itself)"
+                      % (N, t_fit, sample, score.upper(), t),
+            "gp_fit_ms": t_fit * 1e3, "argmax1": int(idx)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as td
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import bot7_amd
+    from bot7_amd import benchmarks, dist
+
+    d, N, M_default, obj_name, score = WORKLOADS[args.workload]
+    M = args.candidates or M_default
+    M_total = M * world
+    ctx = bot7_amd.Context(local_rank)
+    info = ctx.device_info()
+
+    # ---- inputs, resident in HBM before the timed region
+    X_obs = ctx.grid_sobol(N, d, 1 + M_total)                      # the N points after the candidate range
+    Y = benchmarks.registry[obj_name](X_obs)
+    amp = float(np.var(Y))
+    hyp = {"lenscale_sq": np.full(d, d / 8.0), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
+    shard = dist.ShardedScorer(ctx, M_total, rank, world)
+    shard.make_sobol(d, skip=1, download=False)
+    fmin = [float(Y.min())]
+    dev = torch.device("cuda", local_rank)
+
+    def step():
+        ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        ctx.gp_predict(download=False)
+        ctx.score_reset()
+        if score == "ei":
+            ctx.score_ei(fmin, 0.0)
+        else:
+            ctx.score_cb()
+        return shard.nominate(1.0, device=dev)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        best = step()
+    ctx.profile_enable(True)   # HIP events around every kernel phase, on the stream the kernels run on
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    phases = {}
+    for ph in ("kxx", "potrf", "trtri", "alpha", "ksx", "post", "score", "argmax"):
+        ms, n = ctx.profile_get(ph)
+        if n:
+            phases[ph] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
+    Npad = (N + 127) // 128 * 128
+    post = phases.get("post", {"ms_total": 0.0, "launches": 0})
+    # dominant kernel: post_kernel.  Algorithmic flops per launch = rows_in_launch * Npad^2 (triangular L^-1
+    # exploited: N^2/2 multiply-adds per candidate); rows per launch = M / launches-per-step.
+    post_launches_per_step = max(1, post["launches"] // max(1, args.steps))
+    rows_per_launch = M / post_launches_per_step
+    flops_per_launch = rows_per_launch * float(N) * float(N)
+    post_avg_s = (post["ms_total"] / post["launches"] * 1e-3) if post["launches"] else float("nan")
+    achieved = flops_per_launch / post_avg_s / 1e12 if post["launches"] else float("nan")
+    ksx = phases.get("ksx")
+    ksx_gbs = None
+    if ksx:
+        ksx_gbs = (M / post_launches_per_step) * (8.0 * Npad + 8.0 * d) / (ksx["ms_avg"] * 1e-3) / 1e9
+    fit_ms = sum(phases[p]["ms_total"] for p in ("kxx", "potrf", "trtri", "alpha") if p in phases) / max(1, args.steps)
+
+    line = {
+        "metric": "EI candidates scored/sec at N=2048,d=32" if args.workload == "metric"
+                  else "%s candidates scored/sec (%s)" % (score.upper(), args.workload),
+        "value": args.steps * M_total / elapsed,
+        "unit": "candidates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %s d=%d, N=%d obs, %d Sobol candidates per GPU (%d total), %s, one hyper "
+                               "sample per step = GP fit + K(X*,X) + posterior mean/var + score + arg-max"
+                               % (args.workload, obj_name, d, N, M, M_total, score.upper()),
+                   "d": d, "n_obs": N, "candidates_per_gpu": M, "candidates_total": M_total, "score": score,
+                   "parallelism": "candidate-sharded x%d, fit replicated, one (value,index) RCCL exchange" % world,
+                   "device": info["name"]},
+        "roofline": {"bound": "mfma", "kernel": "post_kernel (posterior variance: L^-1 K*' with fused column sumsq)",
+                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS if achieved == achieved else None,
+                     "traffic": None,
+                     "flops_per_launch": flops_per_launch, "avg_launch_ms": post_avg_s * 1e3,
+                     "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s (measured 74.5-77.3, profiles/r01_mfma_f64_probe.txt)"},
+        "gp_fit_ms": fit_ms,
+        "ksx_hbm_gbs": ksx_gbs, "ksx_hbm_frac": (ksx_gbs / HBM_PEAK_GBS) if ksx_gbs else None,
+        "phases": phases,
+        "best": {"value": best[0], "index1": best[1]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(d, N, obj_name, score, args.cpu_sample, X_obs, Y, hyp)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+"""bot7_amd -- MI355X (gfx950) implementation of bot7's GP-posterior + acquisition-scoring hot path.
+
+The numerical work lives in ``libbot7hip.so`` (hand-written HIP kernels behind the C ABI of
+``include/bot7hip.h``).  This package is the host-side mirror of the reference's plug-in protocol
+(``bot7.grids`` / ``bot7.models`` / ``bot7.scores`` and the ``bots.bayesopt`` driver that calls them), so that
+the reference's usage reads the same here:
+
+    from bot7_amd import grids, models, scores, bots
+
+There is no CPU fallback: importing the package is cheap, but the first call that needs the device loads
+the library and raises ``Bot7HipError`` if it, or a gfx950 GPU, is missing.
+"""
+from ._lib import Bot7HipError, Context, default_context, lib_path  # noqa: F401
+from . import grids, models, scores, bots, utils, benchmarks  # noqa: F401
+
+__all__ = ["Bot7HipError", "Context", "default_context", "lib_path", "grids", "models", "scores", "bots", "utils",
+           "benchmarks"]

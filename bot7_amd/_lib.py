@@ -1,0 +1,353 @@
+"""ctypes binding of libbot7hip.so (include/bot7hip.h) and a thin ``Context`` wrapper.
+
+No fallbacks: if the shared library is missing or no gfx950 device is present, the first use raises
+``Bot7HipError``.  Nothing in this package computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbot7hip.so")
+
+B7_OK = 0
+ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7_ERR_STATE",
+             -5: "B7_ERR_UNSUPPORTED", -6: "B7_ERR_RANGE"}
+
+# Every symbol include/bot7hip.h declares (tests check the library exports each of them).
+SYMBOLS = [
+    "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
+    "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
+    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_download",
+    "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
+    "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
+]
+
+
+class Bot7HipError(RuntimeError):
+    def __init__(self, code, message):
+        self.code = code
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "B7_ERR"), code, message))
+
+
+class Hyp(C.Structure):
+    _fields_ = [("lenscale_sq", C.POINTER(C.c_double)), ("amp", C.c_double), ("noise", C.c_double),
+                ("mean", C.c_double)]
+
+
+class GpOpts(C.Structure):
+    _fields_ = [("jitter_eps", C.c_double), ("jitter_growth", C.c_double), ("var_with_noise", C.c_int),
+                ("var_clamp", C.c_int), ("var_min", C.c_double)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def load():
+    """Load libbot7hip.so once.  torch (when installed) is imported first so that both share ONE HIP runtime:
+    torch bundles its own libamdhip64 with the same SONAME, and whichever is mapped first serves both."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise Bot7HipError(-2, "%s not found: build it with `python -m bot7_amd.build` "
+                               "(there is no CPU fallback)" % _SO)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    dp, vp, i64, i32, dbl = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_int, C.c_double
+    sig = {
+        "b7_abi_version": (i32, []),
+        "b7_create": (i32, [C.POINTER(vp), i32]),
+        "b7_destroy": (None, [vp]),
+        "b7_last_error": (C.c_char_p, [vp]),
+        "b7_device_info": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i64)]),
+        "b7_sync": (i32, [vp]),
+        "b7_set_workspace": (i32, [vp, i64]),
+        "b7_sobol_direction_numbers": (i32, [i32, vp]),
+        "b7_grid_sobol": (i32, [vp, i64, i32, i64, vp, vp, vp]),
+        "b7_grid_random": (i32, [vp, i64, i32, C.c_uint64, i64, vp, vp, vp]),
+        "b7_grid_upload": (i32, [vp, vp, i64, i32]),
+        "b7_grid_download": (i32, [vp, i64, i64, vp]),
+        "b7_grid_shape": (i32, [vp, C.POINTER(i64), C.POINTER(i32)]),
+        "b7_grid_remove": (i32, [vp, i64, vp]),
+        "b7_gp_default_opts": (i32, [C.POINTER(GpOpts)]),
+        "b7_gp_set_opts": (i32, [vp, C.POINTER(GpOpts)]),
+        "b7_gp_fit": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(Hyp), vp, C.POINTER(dbl), C.POINTER(i32)]),
+        "b7_gp_predict": (i32, [vp, vp, vp]),
+        "b7_gp_predict_at": (i32, [vp, vp, i64, vp, vp]),
+        "b7_gp_download": (i32, [vp, vp, vp, vp]),
+        "b7_score_reset": (i32, [vp]),
+        "b7_score_ei": (i32, [vp, vp, dbl]),
+        "b7_score_cb": (i32, [vp, dbl, i32, dbl]),
+        "b7_score_finish": (i32, [vp, dbl, C.POINTER(dbl), C.POINTER(i64), vp]),
+        "b7_ei_compute": (i32, [vp, vp, vp, vp, dbl, i64, i32, vp]),
+        "b7_cb_compute": (i32, [vp, vp, vp, dbl, i32, dbl, i64, i32, vp]),
+        "b7_argmax": (i32, [vp, vp, i64, C.POINTER(dbl), C.POINTER(i64)]),
+        "b7_timer_start": (i32, [vp, i32]),
+        "b7_timer_stop": (i32, [vp, i32]),
+        "b7_timer_ms": (i32, [vp, i32, C.POINTER(C.c_float)]),
+        "b7_profile_enable": (i32, [vp, i32]),
+        "b7_profile_reset": (i32, [vp]),
+        "b7_profile_get": (i32, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context(object):
+    """One GPU's worth of state: the resident candidate grid, the current GP fit, the score accumulator."""
+
+    def __init__(self, device_id=0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.b7_create(C.byref(h), int(device_id))
+        if rc != B7_OK:
+            raise Bot7HipError(rc, (self._L.b7_last_error(None) or b"").decode())
+        self._h = h
+        self.device_id = int(device_id)
+        self.grid_version = 0  # bumped whenever the resident grid changes (DeviceGrid views compare against it)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.b7_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != B7_OK:
+            raise Bot7HipError(rc, (self._L.b7_last_error(self._h) or b"").decode())
+
+    # ---- context
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        cus, mem = C.c_int(), C.c_int64()
+        self._ck(self._L.b7_device_info(self._h, name, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+    def sync(self):
+        self._ck(self._L.b7_sync(self._h))
+
+    def set_workspace(self, nbytes):
+        self._ck(self._L.b7_set_workspace(self._h, int(nbytes)))
+
+    # ---- grids
+    @staticmethod
+    def _minmax(mins, maxes, dims):
+        if mins is None and maxes is None:
+            return None, None
+        if mins is None or maxes is None:
+            raise Bot7HipError(-5, "give both mins and maxes or neither")
+        mn, mx = _f64(mins).ravel(), _f64(maxes).ravel()
+        if mn.size != dims or mx.size != dims:
+            raise Bot7HipError(-1, "mins/maxes must have `dims` entries")
+        return mn, mx
+
+    def grid_sobol(self, size, dims, skip=1, mins=None, maxes=None, download=True):
+        mn, mx = self._minmax(mins, maxes, dims)
+        out = np.empty((size, dims), dtype=np.float64) if download else None
+        self._ck(self._L.b7_grid_sobol(self._h, int(size), int(dims), int(skip), _ptr(mn), _ptr(mx), _ptr(out)))
+        self.grid_version += 1
+        return out
+
+    def grid_random(self, size, dims, seed=0, row_offset=0, mins=None, maxes=None, download=True):
+        mn, mx = self._minmax(mins, maxes, dims)
+        out = np.empty((size, dims), dtype=np.float64) if download else None
+        self._ck(self._L.b7_grid_random(self._h, int(size), int(dims), int(seed) & (2 ** 64 - 1), int(row_offset),
+                                        _ptr(mn), _ptr(mx), _ptr(out)))
+        self.grid_version += 1
+        return out
+
+    def grid_upload(self, X):
+        X = _f64(X)
+        if X.ndim != 2:
+            raise Bot7HipError(-1, "grid must be 2-D")
+        self._ck(self._L.b7_grid_upload(self._h, _ptr(X), X.shape[0], X.shape[1]))
+        self.grid_version += 1
+
+    def grid_shape(self):
+        M, d = C.c_int64(), C.c_int()
+        self._ck(self._L.b7_grid_shape(self._h, C.byref(M), C.byref(d)))
+        return M.value, d.value
+
+    def grid_download(self, row0=0, rows=None):
+        M, d = self.grid_shape()
+        rows = M - row0 if rows is None else rows
+        out = np.empty((rows, d), dtype=np.float64)
+        self._ck(self._L.b7_grid_download(self._h, int(row0), int(rows), _ptr(out)))
+        return out
+
+    def grid_remove(self, idx1):
+        _, d = self.grid_shape()
+        row = np.empty(d, dtype=np.float64)
+        self._ck(self._L.b7_grid_remove(self._h, int(idx1), _ptr(row)))
+        self.grid_version += 1
+        return row
+
+    # ---- model
+    def gp_set_opts(self, **kw):
+        o = GpOpts()
+        self._ck(self._L.b7_gp_default_opts(C.byref(o)))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise Bot7HipError(-1, "unknown gp option %r" % k)
+            setattr(o, k, v)
+        self._ck(self._L.b7_gp_set_opts(self._h, C.byref(o)))
+
+    def gp_fit(self, X_obs, Y_obs, lenscale_sq, amp, noise, mean, want_nll=False):
+        X = _f64(X_obs)
+        if X.ndim == 1:
+            X = X.reshape(1, -1)
+        N, d = X.shape
+        Y = _f64(Y_obs).reshape(N, -1)
+        ls = _f64(lenscale_sq).ravel()
+        if ls.size != d:
+            raise Bot7HipError(-1, "lenscale_sq must have d entries")
+        hyp = Hyp(ls.ctypes.data_as(C.POINTER(C.c_double)), float(amp), float(noise), float(mean))
+        nll = np.empty(Y.shape[1], dtype=np.float64) if want_nll else None
+        jit, info = C.c_double(), C.c_int()
+        self._ck(self._L.b7_gp_fit(self._h, _ptr(X), _ptr(Y), N, d, Y.shape[1], C.byref(hyp), _ptr(nll),
+                                   C.byref(jit), C.byref(info)))
+        return {"nll": nll, "jitter": jit.value, "info": info.value}
+
+    def gp_predict(self, download=True):
+        M, _ = self.grid_shape()
+        if not download:
+            self._ck(self._L.b7_gp_predict(self._h, None, None))
+            return None, None
+        mean = np.empty((M, 1), dtype=np.float64)
+        var = np.empty(M, dtype=np.float64)
+        self._ck(self._L.b7_gp_predict(self._h, _ptr(mean), _ptr(var)))
+        return mean, var
+
+    def gp_predict_at(self, X1):
+        X1 = _f64(X1)
+        if X1.ndim == 1:
+            X1 = X1.reshape(1, -1)
+        mean = np.empty((X1.shape[0], 1), dtype=np.float64)
+        var = np.empty(X1.shape[0], dtype=np.float64)
+        self._ck(self._L.b7_gp_predict_at(self._h, _ptr(X1), X1.shape[0], _ptr(mean), _ptr(var)))
+        return mean, var
+
+    def gp_download(self, N, ycols=1):
+        Lh = np.empty((N, N), dtype=np.float64)
+        al = np.empty((N, ycols), dtype=np.float64)
+        Li = np.empty((N, N), dtype=np.float64)
+        self._ck(self._L.b7_gp_download(self._h, _ptr(Lh), _ptr(al), _ptr(Li)))
+        return Lh, al, Li
+
+    # ---- scores
+    def score_reset(self):
+        self._ck(self._L.b7_score_reset(self._h))
+
+    def score_ei(self, fmin, tradeoff=0.0):
+        f = _f64(fmin).ravel()
+        self._ck(self._L.b7_score_ei(self._h, _ptr(f), float(tradeoff)))
+
+    def score_cb(self, tradeoff=1.0, upper=False, sign=-1.0):
+        self._ck(self._L.b7_score_cb(self._h, float(tradeoff), int(bool(upper)), float(sign)))
+
+    def score_finish(self, divisor=1.0, download=False):
+        v, i = C.c_double(), C.c_int64()
+        out = None
+        if download:
+            M, _ = self.grid_shape()
+            out = np.empty(M, dtype=np.float64)
+        self._ck(self._L.b7_score_finish(self._h, float(divisor), C.byref(v), C.byref(i), _ptr(out)))
+        return v.value, i.value, out
+
+    def ei_compute(self, mean, var, fmin, tradeoff=0.0):
+        mean = _f64(mean)
+        M = mean.shape[0]
+        c = 1 if mean.ndim == 1 else mean.shape[1]
+        var, fmin = _f64(var).ravel(), _f64(fmin).ravel()
+        out = np.empty(M, dtype=np.float64)
+        self._ck(self._L.b7_ei_compute(self._h, _ptr(mean), _ptr(var), _ptr(fmin), float(tradeoff), M, c, _ptr(out)))
+        return out
+
+    def cb_compute(self, mean, var, tradeoff=1.0, upper=False, sign=-1.0):
+        mean = _f64(mean)
+        M = mean.shape[0]
+        c = 1 if mean.ndim == 1 else mean.shape[1]
+        var = _f64(var).ravel()
+        out = np.empty(M, dtype=np.float64)
+        self._ck(self._L.b7_cb_compute(self._h, _ptr(mean), _ptr(var), float(tradeoff), int(bool(upper)), float(sign),
+                                       M, c, _ptr(out)))
+        return out
+
+    def argmax(self, scores):
+        s = _f64(scores).ravel()
+        v, i = C.c_double(), C.c_int64()
+        self._ck(self._L.b7_argmax(self._h, _ptr(s), s.shape[0], C.byref(v), C.byref(i)))
+        return v.value, i.value
+
+    # ---- measurement
+    def timer_start(self, slot=0):
+        self._ck(self._L.b7_timer_start(self._h, slot))
+
+    def timer_stop(self, slot=0):
+        self._ck(self._L.b7_timer_stop(self._h, slot))
+
+    def timer_ms(self, slot=0):
+        ms = C.c_float()
+        self._ck(self._L.b7_timer_ms(self._h, slot, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._ck(self._L.b7_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._ck(self._L.b7_profile_reset(self._h))
+
+    def profile_get(self, phase):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._L.b7_profile_get(self._h, phase.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def sobol_direction_numbers(dims):
+    """Host-only view of the Sobol direction-number table the kernel uses (no GPU needed)."""
+    out = np.empty((dims, 30), dtype=np.uint32)
+    rc = load().b7_sobol_direction_numbers(int(dims), _ptr(out))
+    if rc != B7_OK:
+        raise Bot7HipError(rc, "dims must be in [1, 39]")
+    return out
+
+
+_default = {}
+
+
+def default_context(device_id=None):
+    """Process-wide context for a device (LOCAL_RANK when launched one process per GPU)."""
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_id not in _default:
+        _default[device_id] = Context(device_id)
+    return _default[device_id]

@@ -1,0 +1,65 @@
+"""bot7.bots.bayesopt (bots/bayesopt.lua): MC-marginalised acquisition over GP hyper samples, then arg-max.
+
+eval (bots/bayesopt.lua:56-82) keeps the reference's arithmetic -- score = zeros(M); per hyper sample
+score:add(acq); score:div(nSamples) -- but the accumulator lives on the GPU (b7_score_reset / _ei|_cb /
+_finish) so no M-vector crosses PCIe per sample; nominate (:85-99) takes the arg-max from the same finish call
+(score:max(1): first maximum, 1-based)."""
+import numpy as np
+
+from .abstract import abstract
+from .. import models as Models
+from .. import scores as Scores
+
+
+class bayesopt(abstract):
+    title = "bot7.bots.bayesopt"
+
+    def __init__(self, objective, hypers, config=None, cache=None):
+        cache = cache or {}
+        super().__init__(objective, hypers, config, cache)
+        config = self.config
+        self.model = cache.get("model") or Models.registry[config["model"]["type"]](config["model"])  # :31
+        self.score = cache.get("score") or Scores.registry[config["score"]["type"]](config["score"])  # :32
+        self._rng = np.random.default_rng(config["bot"]["seed"])
+        self.last_scores = None
+
+    def configure(self, config):
+        config = super().configure(config)
+        model = dict(config.get("model") or {})
+        model.setdefault("type", "gp_regressor")        # bots/bayesopt.lua:40
+        model.setdefault("kernel", "ardse")             # :41
+        model.setdefault("nzModel", "GaussianNoise_iso")  # :42
+        model.setdefault("mean", "constant")            # :43
+        model.setdefault("sampler", "slice")            # :44
+        config["model"] = model
+        score = dict(config.get("score") or {})
+        score.setdefault("type", "expected_improvement")  # :49
+        config["score"] = score
+        return config
+
+    def eval(self, candidates=None, want_scores=True):
+        """bots/bayesopt.lua:56-82.  Returns (scores or None, best_value, best_index_1based)."""
+        X_obs, Y_obs = self.observed, self.responses
+        X_hid = self.candidates if candidates is None else candidates
+        model, ctx = self.model, self.model.ctx
+        model.sample_hypers(X_obs, Y_obs)                         # :68 (burn-in call)
+        nSamples = self.config["bot"]["nSamples"]
+        first = True
+        for _ in range(nSamples):                                 # :73-78
+            hyp = model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True))
+            model.predict_device(X_obs, Y_obs, X_hid, hyp)        # inside score(...) -> model:predict
+            if first:
+                ctx.score_reset()                                 # :69 torch.zeros(M)
+                first = False
+            self.score.add_to(ctx, Y_obs)                         # :76 score:add(...)
+        val, idx, scores = ctx.score_finish(float(nSamples), download=want_scores)  # :79 div, :96 max
+        self.last_scores = scores
+        return scores, val, idx
+
+    def nominate(self, candidates=None):
+        """bots/bayesopt.lua:85-99."""
+        cand = self.candidates if candidates is None else candidates
+        if self.nTrials <= self.config["bot"]["nInitial"]:        # :90-91 floor(rand*M)+1
+            return int(np.floor(self._rng.random() * cand.shape[0])) + 1
+        _, _, idx = self.eval(cand, want_scores=False)            # :95-96
+        return idx

@@ -1,0 +1,615 @@
+// C-ABI entry points of libbot7hip.so (declared in include/bot7hip.h) and the context behind them.
+// Host-side orchestration only: every number is produced by the kernels in sobol/covar/potrf/posterior/
+// score.hip.  There is no CPU fallback: without a working HIP device b7_create fails and nothing else runs.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "b7_internal.h"
+
+static thread_local std::string g_create_err;
+
+int b7_fail(b7_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_err = buf;
+  return code;
+}
+
+int b7_ensure(b7_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.cap >= bytes) return B7_OK;
+  if (b.p) {
+    // keep stream order: nothing in flight may still use the old block
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    B7_HIP(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return b7_fail(c, B7_ERR_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+  }
+  b.cap = bytes;
+  return B7_OK;
+}
+
+void b7_release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+PhaseScope::PhaseScope(b7_ctx *c_, const char *name_) : c(c_), name(name_) {
+  if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
+}
+PhaseScope::~PhaseScope() {
+  if (!c->profile) return;
+  (void)hipEventRecord(c->pev[1], c->stream);
+  (void)hipEventSynchronize(c->pev[1]);
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, c->pev[0], c->pev[1]) == hipSuccess) {
+    PhaseStat &s = c->phases[name];
+    s.ms += ms;
+    s.launches += 1;
+  }
+}
+
+static double *cur_grid(b7_ctx *c) { return (double *)c->grid[c->grid_cur].p; }
+
+static void invalidate_predictions(b7_ctx *c) {
+  c->predicted = false;
+  c->acc_valid = false;
+}
+
+extern "C" {
+
+int b7_abi_version(void) { return B7_ABI_VERSION; }
+
+int b7_create(b7_ctx **out, int device_id) {
+  if (!out) return b7_fail(nullptr, B7_ERR_INVALID, "b7_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return b7_fail(nullptr, B7_ERR_HIP, "no HIP device available (%s); libbot7hip has no CPU path",
+                   e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev)
+    return b7_fail(nullptr, B7_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, ndev);
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return b7_fail(nullptr, B7_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return b7_fail(nullptr, B7_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return b7_fail(nullptr, B7_ERR_UNSUPPORTED, "device %d is %s; libbot7hip is built for gfx950 only", device_id,
+                   prop.gcnArchName);
+  b7_ctx *c = new b7_ctx();
+  c->device = device_id;
+  c->cus = prop.multiProcessorCount;
+  b7_gp_default_opts(&c->opts);
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->pev[0]);
+  if (e == hipSuccess) e = hipEventCreate(&c->pev[1]);
+  if (e != hipSuccess) {
+    delete c;
+    return b7_fail(nullptr, B7_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
+  }
+  // fixed scratch: [0,1K) lengthscales, [2K,4K) fmin, [4K,...) Sobol table + mins/maxes; never regrown
+  if (b7_ensure(c, c->scratch, 64 * 1024) != B7_OK) {
+    g_create_err = c->err;
+    b7_destroy(c);
+    return B7_ERR_NOMEM;
+  }
+  *out = c;
+  return B7_OK;
+}
+
+void b7_destroy(b7_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
+                   &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar};
+  for (DevBuf *b : all) b7_release(*b);
+  if (c->tev_init)
+    for (int i = 0; i < B7_MAX_TIMERS; ++i) {
+      (void)hipEventDestroy(c->tev[i][0]);
+      (void)hipEventDestroy(c->tev[i][1]);
+    }
+  (void)hipEventDestroy(c->pev[0]);
+  (void)hipEventDestroy(c->pev[1]);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *b7_last_error(const b7_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int b7_device_info(b7_ctx *c, char *name_out, int *compute_units, int64_t *hbm_bytes) {
+  if (!c) return B7_ERR_INVALID;
+  hipDeviceProp_t prop;
+  B7_HIP(c, hipGetDeviceProperties(&prop, c->device));
+  if (name_out) snprintf(name_out, 64, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return B7_OK;
+}
+
+int b7_sync(b7_ctx *c) {
+  if (!c) return B7_ERR_INVALID;
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_set_workspace(b7_ctx *c, int64_t bytes) {
+  if (!c || bytes < (int64_t)(8 * 128 * 128)) return c ? b7_fail(c, B7_ERR_INVALID, "workspace too small") : B7_ERR_INVALID;
+  c->ks_bytes = (size_t)bytes;
+  return B7_OK;
+}
+
+// ---- grids ---------------------------------------------------------------------------------------------
+static int grid_alloc(b7_ctx *c, int64_t M, int d) {
+  if (M < 0 || d < 1) return b7_fail(c, B7_ERR_INVALID, "grid: size %lld dims %d", (long long)M, d);
+  if (d > B7_MAX_D) return b7_fail(c, B7_ERR_UNSUPPORTED, "grid: dims %d > %d", d, B7_MAX_D);
+  B7_HIP(c, hipSetDevice(c->device));
+  c->grid_cur = 0;
+  B7_TRY(b7_ensure(c, c->grid[0], sizeof(double) * (size_t)M * d));
+  c->M = M;
+  c->d = d;
+  invalidate_predictions(c);
+  return B7_OK;
+}
+
+static int grid_copy_out(b7_ctx *c, double *out_host) {
+  if (out_host && c->M > 0)
+    B7_HIP(c, hipMemcpyAsync(out_host, cur_grid(c), sizeof(double) * (size_t)c->M * c->d, hipMemcpyDeviceToHost,
+                             c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_grid_sobol(b7_ctx *c, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
+                  double *out_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (size < 0) return b7_fail(c, B7_ERR_INVALID, "sobol: size %lld", (long long)size);
+  if (dims < 1 || dims >= 40)  // assert(C.dims and C.dims < C.max_dims), grids/sobol.lua:36
+    return b7_fail(c, B7_ERR_RANGE, "sobol: dims %d not in [1, 39] (grids/sobol.lua:36)", dims);
+  if ((mins == nullptr) != (maxes == nullptr))
+    return b7_fail(c, B7_ERR_UNSUPPORTED, "sobol: give both mins and maxes or neither");
+  // "Too many calls": lo0(seed) must stay <= 30 (grids/sobol.lua:317-324) -> seed <= 2^30 - 2
+  if (size > 0 && size + skip - 1 > ((int64_t)1 << 30) - 2)
+    return b7_fail(c, B7_ERR_RANGE, "sobol: point index %lld beyond 2^30-2 (grids/sobol.lua:317-324)",
+                   (long long)(size + skip - 1));
+  B7_TRY(grid_alloc(c, size, dims));
+  B7_TRY(launch_sobol(c, cur_grid(c), size, dims, skip, mins, maxes));
+  return grid_copy_out(c, out_host);
+}
+
+int b7_grid_random(b7_ctx *c, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins,
+                   const double *maxes, double *out_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (size < 0 || row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "random grid: size/offset negative");
+  if ((mins == nullptr) != (maxes == nullptr))
+    return b7_fail(c, B7_ERR_UNSUPPORTED, "random grid: give both mins and maxes or neither");
+  B7_TRY(grid_alloc(c, size, dims));
+  B7_TRY(launch_random_grid(c, cur_grid(c), size, dims, seed, row_offset, mins, maxes));
+  return grid_copy_out(c, out_host);
+}
+
+int b7_grid_upload(b7_ctx *c, const double *X, int64_t M, int d) {
+  if (!c) return B7_ERR_INVALID;
+  if (!X && M > 0) return b7_fail(c, B7_ERR_INVALID, "grid_upload: X is NULL");
+  B7_TRY(grid_alloc(c, M, d));
+  if (M > 0)
+    B7_HIP(c, hipMemcpyAsync(cur_grid(c), X, sizeof(double) * (size_t)M * d, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_grid_download(b7_ctx *c, int64_t row0, int64_t rows, double *out_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (row0 < 0 || rows < 0 || row0 + rows > c->M || (!out_host && rows > 0))
+    return b7_fail(c, B7_ERR_INVALID, "grid_download: rows [%lld, %lld) outside [0, %lld)", (long long)row0,
+                   (long long)(row0 + rows), (long long)c->M);
+  if (rows > 0)
+    B7_HIP(c, hipMemcpyAsync(out_host, cur_grid(c) + row0 * c->d, sizeof(double) * (size_t)rows * c->d,
+                             hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_grid_shape(b7_ctx *c, int64_t *M, int *d) {
+  if (!c) return B7_ERR_INVALID;
+  if (M) *M = c->M;
+  if (d) *d = c->d;
+  return B7_OK;
+}
+
+int b7_grid_remove(b7_ctx *c, int64_t idx1, double *row_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (idx1 < 1 || idx1 > c->M)
+    return b7_fail(c, B7_ERR_INVALID, "grid_remove: index %lld outside [1, %lld]", (long long)idx1, (long long)c->M);
+  B7_HIP(c, hipSetDevice(c->device));
+  if (row_out)
+    B7_HIP(c, hipMemcpyAsync(row_out, cur_grid(c) + (idx1 - 1) * c->d, sizeof(double) * c->d, hipMemcpyDeviceToHost,
+                             c->stream));
+  const int other = c->grid_cur ^ 1;
+  B7_TRY(b7_ensure(c, c->grid[other], sizeof(double) * (size_t)c->M * c->d));
+  B7_TRY(launch_remove_row(c, cur_grid(c), (double *)c->grid[other].p, c->M, c->d, idx1 - 1));
+  c->grid_cur = other;
+  c->M -= 1;
+  invalidate_predictions(c);
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------------------
+int b7_gp_default_opts(b7_gp_opts *o) {
+  if (!o) return B7_ERR_INVALID;
+  o->jitter_eps = 1e-8;     // utils/math.lua:175
+  o->jitter_growth = 1.1;   // utils/math.lua:176
+  o->var_with_noise = 0;
+  o->var_clamp = 0;
+  o->var_min = 0.0;
+  return B7_OK;
+}
+
+int b7_gp_set_opts(b7_ctx *c, const b7_gp_opts *o) {
+  if (!c || !o) return B7_ERR_INVALID;
+  if (!(o->jitter_eps > 0.0) || !(o->jitter_growth > 1.0))
+    return b7_fail(c, B7_ERR_INVALID, "gp opts: jitter_eps must be > 0 and jitter_growth > 1");
+  c->opts = *o;
+  return B7_OK;
+}
+
+// One factorisation attempt of K + extra*I; returns dpotrf-style info through *info.
+static int try_factor(b7_ctx *c, double extra, int *info);
+
+int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,
+              double *nll_out, double *jitter_used, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!X || !Y || !hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit: NULL argument");
+  if (N < 1 || d < 1 || ycols < 1) return b7_fail(c, B7_ERR_INVALID, "gp_fit: N %d d %d ycols %d", N, d, ycols);
+  if (d > B7_MAX_D) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: d %d > %d", d, B7_MAX_D);
+  if (ycols != 1) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: ycols %d (fantasies) not built yet", ycols);
+  for (int k = 0; k < d; ++k)
+    if (!(hyp->lenscale_sq[k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: lenscale_sq[%d] must be > 0", k);
+  if (!(hyp->amp > 0.0) || !(hyp->noise >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: amp > 0, noise >= 0");
+  B7_HIP(c, hipSetDevice(c->device));
+
+  c->fitted = false;
+  invalidate_predictions(c);
+  c->N = N;
+  c->Npad = (int)round_up(N, B7_NPAD);
+  c->dfit = d;
+  c->dpad = (int)round_up(d, 4);
+  c->ycols = ycols;
+  c->amp = hyp->amp;
+  c->noise = hyp->noise;
+  c->mean = hyp->mean;
+  const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
+  B7_TRY(b7_ensure(c, c->xobs, sizeof(double) * (size_t)N * d));
+  B7_TRY(b7_ensure(c, c->w, sizeof(double) * c->dpad));
+  B7_TRY(b7_ensure(c, c->zsc, sizeof(double) * np * c->dpad));
+  B7_TRY(b7_ensure(c, c->zss, sizeof(double) * np));
+  B7_TRY(b7_ensure(c, c->K, nn));
+  B7_TRY(b7_ensure(c, c->L, nn));
+  B7_TRY(b7_ensure(c, c->Linv, nn));
+  B7_TRY(b7_ensure(c, c->W, nn));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np * ycols));
+  B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np * ycols));
+  B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
+
+  // uploads (stream-ordered; the pageable source is consumed before the call returns via the sync below)
+  double *ls_dev = (double *)c->scratch.p;  // first 4096 bytes of scratch: up to 512 doubles
+  B7_HIP(c, hipMemcpyAsync(c->xobs.p, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipMemcpyAsync(ls_dev, hyp->lenscale_sq, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
+  std::vector<double> r(np * ycols, 0.0);
+  for (size_t i = 0; i < (size_t)N * ycols; ++i) r[i] = Y[i] - hyp->mean;
+  B7_HIP(c, hipMemcpyAsync(c->resid.p, r.data(), sizeof(double) * np * ycols, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
+  B7_TRY(launch_kxx(c, hyp->noise));
+
+  // utils/math.lua:159-218: plain attempt, then the growing-jitter retries on the ORIGINAL matrix.
+  int info = 0;
+  B7_TRY(try_factor(c, 0.0, &info));
+  const int info_first = info;
+  double jitter = 0.0;
+  if (info != 0) {
+    // max_eps = src:norm() (Frobenius) of the N x N matrix that was handed to chol (:174)
+    std::vector<double> Kh((size_t)N * N);
+    B7_HIP(c, hipMemcpy2D(Kh.data(), sizeof(double) * N, c->K.p, sizeof(double) * np, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+    double fro = 0.0;
+    for (double v : Kh) fro += v * v;
+    const double max_eps = sqrt(fro);
+    if (max_eps != max_eps)  // the reference's while-loop never ends here (eps > NaN is false); fail instead
+      return b7_fail(c, B7_ERR_INVALID, "gp_fit: K(X,X) contains NaN (check X_obs and the hyper-parameters)");
+    double eps = c->opts.jitter_eps;
+    for (;;) {
+      if (eps > max_eps) {  // :184-186 chol(I)
+        jitter = -1.0;
+        std::vector<double> eye(np * np, 0.0);
+        for (size_t i = 0; i < np; ++i) eye[i * np + i] = 1.0;
+        B7_HIP(c, hipMemcpy(c->L.p, eye.data(), nn, hipMemcpyHostToDevice));
+        std::vector<double> di(np * B7_PANEL, 0.0);
+        for (size_t b = 0; b < np / B7_PANEL; ++b)
+          for (int i = 0; i < B7_PANEL; ++i) di[b * B7_PANEL * B7_PANEL + i * B7_PANEL + i] = 1.0;
+        B7_HIP(c, hipMemcpy(c->dinv.p, di.data(), sizeof(double) * np * B7_PANEL, hipMemcpyHostToDevice));
+        break;
+      }
+      eps = eps * c->opts.jitter_growth;  // :188
+      B7_TRY(try_factor(c, eps, &info));
+      if (info == 0) {
+        jitter = eps;
+        break;
+      }
+    }
+  }
+  B7_TRY(launch_trtri(c));
+  B7_TRY(launch_alpha(c));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+
+  if (nll_out) {
+    std::vector<double> diag(N), al((size_t)N * ycols);
+    B7_HIP(c, hipMemcpy2D(diag.data(), sizeof(double), c->L.p, sizeof(double) * (np + 1), sizeof(double), N,
+                          hipMemcpyDeviceToHost));
+    B7_HIP(c, hipMemcpy(al.data(), c->alpha.p, sizeof(double) * (size_t)N * ycols, hipMemcpyDeviceToHost));
+    double logdet = 0.0;
+    for (int i = 0; i < N; ++i) logdet += log(diag[i]);
+    for (int k = 0; k < ycols; ++k) {
+      double q = 0.0;
+      for (int i = 0; i < N; ++i) q += r[(size_t)i * ycols + k] * al[(size_t)i * ycols + k];
+      nll_out[k] = 0.5 * q + logdet + 0.5 * N * log(2.0 * M_PI);
+    }
+  }
+  if (jitter_used) *jitter_used = jitter;
+  if (info_out) *info_out = info_first;
+  c->fitted = true;
+  return B7_OK;
+}
+
+}  // extern "C"
+
+static int try_factor(b7_ctx *c, double extra, int *info) {
+  B7_TRY(launch_potrf(c, extra));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
+  B7_HIP(c, hipMemcpyAsync(info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+extern "C" {
+
+static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, double *var) {
+  if (M == 0) return B7_OK;
+  const size_t row_bytes = sizeof(double) * (size_t)c->Npad;
+  int64_t chunk = (int64_t)(c->ks_bytes / row_bytes) / B7_MROWS * B7_MROWS;
+  if (chunk < B7_MROWS) chunk = B7_MROWS;
+  const int64_t Mpad = round_up(M, B7_MROWS);
+  if (chunk > Mpad) chunk = Mpad;
+  B7_TRY(b7_ensure(c, c->ks, (size_t)chunk * row_bytes));
+  for (int64_t row0 = 0; row0 < M; row0 += chunk) {
+    int64_t rows = Mpad - row0 < chunk ? Mpad - row0 : chunk;
+    B7_TRY(launch_ksx(c, xq, row0, rows, M, c->dfit, (double *)c->ks.p, mu, c->ycols));
+    B7_TRY(launch_post(c, (const double *)c->ks.p, row0, rows, M, var));
+  }
+  return B7_OK;
+}
+
+int b7_gp_predict(b7_ctx *c, double *mean_host, double *var_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_predict: no fit on this context");
+  if (c->M <= 0) return b7_fail(c, B7_ERR_STATE, "gp_predict: no candidate grid on this context");
+  if (c->d != c->dfit) return b7_fail(c, B7_ERR_INVALID, "gp_predict: grid dims %d != fit dims %d", c->d, c->dfit);
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M * c->ycols));
+  B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
+  B7_TRY(predict_into(c, cur_grid(c), c->M, (double *)c->mu.p, (double *)c->var.p));
+  c->predicted = true;
+  c->Mpred = c->M;
+  if (mean_host)
+    B7_HIP(c, hipMemcpyAsync(mean_host, c->mu.p, sizeof(double) * (size_t)c->M * c->ycols, hipMemcpyDeviceToHost,
+                             c->stream));
+  if (var_host)
+    B7_HIP(c, hipMemcpyAsync(var_host, c->var.p, sizeof(double) * (size_t)c->M, hipMemcpyDeviceToHost, c->stream));
+  if (mean_host || var_host) B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_gp_predict_at(b7_ctx *c, const double *X1, int64_t M1, double *mean_host, double *var_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_predict_at: no fit on this context");
+  if (M1 < 0 || (!X1 && M1 > 0)) return b7_fail(c, B7_ERR_INVALID, "gp_predict_at: bad X1/M1");
+  if (M1 == 0) return B7_OK;
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)M1 * c->dfit));
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * (size_t)M1 * c->ycols));
+  B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)M1));
+  B7_HIP(c, hipMemcpyAsync(c->tmpgrid.p, X1, sizeof(double) * (size_t)M1 * c->dfit, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(predict_into(c, (const double *)c->tmpgrid.p, M1, (double *)c->tmpmu.p, (double *)c->tmpvar.p));
+  if (mean_host)
+    B7_HIP(c, hipMemcpyAsync(mean_host, c->tmpmu.p, sizeof(double) * (size_t)M1 * c->ycols, hipMemcpyDeviceToHost,
+                             c->stream));
+  if (var_host)
+    B7_HIP(c, hipMemcpyAsync(var_host, c->tmpvar.p, sizeof(double) * (size_t)M1, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_gp_download(b7_ctx *c, double *L_host, double *alpha_host, double *Linv_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_download: no fit on this context");
+  const size_t N = c->N, np = c->Npad;
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (L_host)
+    B7_HIP(c, hipMemcpy2D(L_host, sizeof(double) * N, c->L.p, sizeof(double) * np, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+  if (Linv_host)
+    B7_HIP(c, hipMemcpy2D(Linv_host, sizeof(double) * N, c->Linv.p, sizeof(double) * np, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+  if (alpha_host)
+    B7_HIP(c, hipMemcpy(alpha_host, c->alpha.p, sizeof(double) * N * c->ycols, hipMemcpyDeviceToHost));
+  return B7_OK;
+}
+
+// ---- scores --------------------------------------------------------------------------------------------
+int b7_score_reset(b7_ctx *c) {
+  if (!c) return B7_ERR_INVALID;
+  if (c->M <= 0) return b7_fail(c, B7_ERR_STATE, "score_reset: no candidate grid");
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
+  B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69
+  c->acc_valid = true;
+  return B7_OK;
+}
+
+static int score_ready(b7_ctx *c, const char *who) {
+  if (!c->predicted || c->Mpred != c->M) return b7_fail(c, B7_ERR_STATE, "%s: call b7_gp_predict first", who);
+  if (!c->acc_valid) return b7_fail(c, B7_ERR_STATE, "%s: call b7_score_reset first", who);
+  return B7_OK;
+}
+
+int b7_score_ei(b7_ctx *c, const double *fmin, double tradeoff) {
+  if (!c) return B7_ERR_INVALID;
+  if (!fmin) return b7_fail(c, B7_ERR_INVALID, "score_ei: fmin is NULL");
+  B7_TRY(score_ready(c, "score_ei"));
+  B7_HIP(c, hipSetDevice(c->device));
+  double *fd = (double *)((char *)c->scratch.p + 2048);
+  B7_HIP(c, hipMemcpyAsync(fd, fmin, sizeof(double) * c->ycols, hipMemcpyHostToDevice, c->stream));
+  return launch_ei(c, (const double *)c->mu.p, (const double *)c->var.p, fd, tradeoff, c->M, c->ycols,
+                   (double *)c->acc.p, true);
+}
+
+int b7_score_cb(b7_ctx *c, double tradeoff, int upper, double sign) {
+  if (!c) return B7_ERR_INVALID;
+  B7_TRY(score_ready(c, "score_cb"));
+  B7_HIP(c, hipSetDevice(c->device));
+  return launch_cb(c, (const double *)c->mu.p, (const double *)c->var.p, tradeoff, upper, sign, c->M, c->ycols,
+                   (double *)c->acc.p, true);
+}
+
+int b7_score_finish(b7_ctx *c, double divisor, double *best_val, int64_t *best_idx1, double *scores_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->acc_valid) return b7_fail(c, B7_ERR_STATE, "score_finish: call b7_score_reset first");
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(launch_finish(c, (double *)c->acc.p, c->M, divisor, best_val, best_idx1));
+  if (scores_host) {
+    B7_HIP(c, hipMemcpyAsync(scores_host, c->acc.p, sizeof(double) * (size_t)c->M, hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return B7_OK;
+}
+
+static int upload_mv(b7_ctx *c, const double *mean, const double *var, int64_t M, int cc) {
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * (size_t)M * cc));
+  B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)M));
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)M));
+  B7_HIP(c, hipMemcpyAsync(c->tmpmu.p, mean, sizeof(double) * (size_t)M * cc, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipMemcpyAsync(c->tmpvar.p, var, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
+  return B7_OK;
+}
+
+int b7_ei_compute(b7_ctx *c, const double *mean, const double *var, const double *fmin, double tradeoff, int64_t M,
+                  int cc, double *out) {
+  if (!c) return B7_ERR_INVALID;
+  if (M < 0 || cc < 1 || cc > 256 || (M > 0 && (!mean || !var || !fmin || !out)))
+    return b7_fail(c, B7_ERR_INVALID, "ei_compute: bad arguments");
+  if (M == 0) return B7_OK;
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(upload_mv(c, mean, var, M, cc));
+  double *fd = (double *)((char *)c->scratch.p + 2048);
+  B7_HIP(c, hipMemcpyAsync(fd, fmin, sizeof(double) * cc, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_ei(c, (const double *)c->tmpmu.p, (const double *)c->tmpvar.p, fd, tradeoff, M, cc,
+                   (double *)c->tmpgrid.p, false));
+  B7_HIP(c, hipMemcpyAsync(out, c->tmpgrid.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_cb_compute(b7_ctx *c, const double *mean, const double *var, double tradeoff, int upper, double sign, int64_t M,
+                  int cc, double *out) {
+  if (!c) return B7_ERR_INVALID;
+  if (M < 0 || cc < 1 || (M > 0 && (!mean || !var || !out))) return b7_fail(c, B7_ERR_INVALID, "cb_compute: bad arguments");
+  if (M == 0) return B7_OK;
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(upload_mv(c, mean, var, M, cc));
+  B7_TRY(launch_cb(c, (const double *)c->tmpmu.p, (const double *)c->tmpvar.p, tradeoff, upper, sign, M, cc,
+                   (double *)c->tmpgrid.p, false));
+  B7_HIP(c, hipMemcpyAsync(out, c->tmpgrid.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_argmax(b7_ctx *c, const double *scores, int64_t M, double *best_val, int64_t *best_idx1) {
+  if (!c) return B7_ERR_INVALID;
+  if (M < 1 || !scores) return b7_fail(c, B7_ERR_INVALID, "argmax: empty input");
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)M));
+  B7_HIP(c, hipMemcpyAsync(c->tmpgrid.p, scores, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
+  return launch_finish(c, (double *)c->tmpgrid.p, M, 1.0, best_val, best_idx1);
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------
+static int timers_init(b7_ctx *c) {
+  if (c->tev_init) return B7_OK;
+  for (int i = 0; i < B7_MAX_TIMERS; ++i) {
+    B7_HIP(c, hipEventCreate(&c->tev[i][0]));
+    B7_HIP(c, hipEventCreate(&c->tev[i][1]));
+  }
+  c->tev_init = true;
+  return B7_OK;
+}
+
+int b7_timer_start(b7_ctx *c, int slot) {
+  if (!c || slot < 0 || slot >= B7_MAX_TIMERS) return B7_ERR_INVALID;
+  B7_TRY(timers_init(c));
+  B7_HIP(c, hipEventRecord(c->tev[slot][0], c->stream));
+  return B7_OK;
+}
+
+int b7_timer_stop(b7_ctx *c, int slot) {
+  if (!c || slot < 0 || slot >= B7_MAX_TIMERS) return B7_ERR_INVALID;
+  B7_TRY(timers_init(c));
+  B7_HIP(c, hipEventRecord(c->tev[slot][1], c->stream));
+  return B7_OK;
+}
+
+int b7_timer_ms(b7_ctx *c, int slot, float *ms_out) {
+  if (!c || slot < 0 || slot >= B7_MAX_TIMERS || !ms_out) return B7_ERR_INVALID;
+  B7_TRY(timers_init(c));
+  B7_HIP(c, hipEventSynchronize(c->tev[slot][1]));
+  B7_HIP(c, hipEventElapsedTime(ms_out, c->tev[slot][0], c->tev[slot][1]));
+  return B7_OK;
+}
+
+int b7_profile_enable(b7_ctx *c, int on) {
+  if (!c) return B7_ERR_INVALID;
+  c->profile = on != 0;
+  return B7_OK;
+}
+
+int b7_profile_reset(b7_ctx *c) {
+  if (!c) return B7_ERR_INVALID;
+  c->phases.clear();
+  return B7_OK;
+}
+
+int b7_profile_get(b7_ctx *c, const char *phase, double *ms_total, int64_t *launches) {
+  if (!c || !phase) return B7_ERR_INVALID;
+  auto it = c->phases.find(phase);
+  if (ms_total) *ms_total = it == c->phases.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == c->phases.end() ? 0 : it->second.launches;
+  return B7_OK;
+}
+
+}  // extern "C"

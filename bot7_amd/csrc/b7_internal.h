@@ -1,0 +1,137 @@
+// Internal declarations shared by the translation units of libbot7hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bot7hip.h"
+
+// Tile constants.  Every matrix dimension that a GEMM-class kernel sees is padded to these.
+constexpr int B7_NPAD = 128;  // observations padded to a multiple of this (post kernel's n-tile)
+constexpr int B7_PANEL = 64;  // Cholesky panel width / small-GEMM tile
+constexpr int B7_MROWS = 128; // candidate rows per post-kernel block; chunk rows are multiples of this
+constexpr int B7_MAX_D = 128; // LDS budget of the covariance kernel: 128 rows x (dpad+2) doubles <= 160 KiB
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct PhaseStat {
+  double ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct b7_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int cus = 0;
+
+  // ---- candidate grid (row-major M x d), ping-pong for stable row removal
+  DevBuf grid[2];
+  int grid_cur = 0;
+  int64_t M = 0;
+  int d = 0;
+
+  // ---- fit state
+  bool fitted = false;
+  int N = 0, Npad = 0, dfit = 0, dpad = 0, ycols = 0;
+  double amp = 0, noise = 0, mean = 0;
+  b7_gp_opts opts;
+  DevBuf xobs;   // N x d raw observations
+  DevBuf w;      // dpad inverse squared lengthscales (0 in the padding)
+  DevBuf zsc;    // Npad x dpad: observations scaled by w (0 in the padding)
+  DevBuf zss;    // Npad: sum z^2 w  (+inf in the padding -> covariance 0)
+  DevBuf K;      // Npad x Npad: K(X,X)+noise*I as assembled (kept for the jitter retries)
+  DevBuf L;      // Npad x Npad: lower Cholesky factor (upper triangle zero)
+  DevBuf Linv;   // Npad x Npad: explicit inverse of L (upper triangle zero)
+  DevBuf W;      // Npad x Npad: scratch of the triangular inversion
+  DevBuf dinv;   // (Npad/64) x 64 x 64: inverses of L's diagonal blocks
+  DevBuf alpha;  // Npad x ycols (0 in the padding)
+  DevBuf resid;  // Npad x ycols: Y - mean, then L^-1 (Y - mean)
+  DevBuf info;   // int[4]: first failing pivot (1-based), 0 if none
+  DevBuf ybuf;   // N x ycols raw
+
+  // ---- predict / score state over the resident grid
+  bool predicted = false;
+  int64_t Mpred = 0;
+  DevBuf mu;     // M x ycols
+  DevBuf var;    // M
+  DevBuf acc;    // M score accumulator
+  bool acc_valid = false;
+  DevBuf ks;     // K(X*,X) chunk workspace
+  size_t ks_bytes = (size_t)4 << 30;
+  DevBuf part;   // argmax partials (value, index)
+  DevBuf scratch; // misc (fmin upload, results)
+  DevBuf tmpgrid; // predict_at temporary grid
+  DevBuf tmpmu, tmpvar;
+
+  // ---- measurement
+  hipEvent_t tev[B7_MAX_TIMERS][2];
+  bool tev_init = false;
+  bool profile = false;
+  std::map<std::string, PhaseStat> phases;
+  hipEvent_t pev[2];
+};
+
+// ---- error helpers ---------------------------------------------------------------------------------
+int b7_fail(b7_ctx *c, int code, const char *fmt, ...);
+#define B7_HIP(c, expr)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return b7_fail((c), e__ == hipErrorOutOfMemory ? B7_ERR_NOMEM : B7_ERR_HIP, "%s: %s", \
+                     #expr, hipGetErrorString(e__));                                        \
+  } while (0)
+#define B7_TRY(expr)          \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != B7_OK) return rc__; \
+  } while (0)
+
+int b7_ensure(b7_ctx *c, DevBuf &b, size_t bytes);
+void b7_release(DevBuf &b);
+
+// Phase timing (no-ops unless profiling is on).
+struct PhaseScope {
+  b7_ctx *c;
+  const char *name;
+  PhaseScope(b7_ctx *c, const char *name);
+  ~PhaseScope();
+};
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- kernel launchers (each enqueues on c->stream and returns a B7 code) ----------------------------
+// sobol.hip
+int launch_sobol(b7_ctx *c, double *out, int64_t size, int dims, int64_t skip, const double *mins,
+                 const double *maxes);
+int launch_random_grid(b7_ctx *c, double *out, int64_t size, int dims, uint64_t seed, int64_t row_offset,
+                       const double *mins, const double *maxes);
+int launch_remove_row(b7_ctx *c, const double *src, double *dst, int64_t M, int d, int64_t idx0);
+
+// covar.hip
+int launch_prep_obs(b7_ctx *c, const double *xobs, const double *lenscale_sq_dev, int N, int d);
+int launch_kxx(b7_ctx *c, double diag_add);
+int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
+               double *mu, int ycols);
+
+// potrf.hip
+int launch_potrf(b7_ctx *c, double extra);  // K + extra*I -> L (writes c->L, c->dinv, c->info)
+int launch_trtri(b7_ctx *c);           // L, dinv -> Linv
+int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
+
+// posterior.hip
+int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var);
+
+// score.hip
+int launch_ei(b7_ctx *c, const double *mu, const double *var, const double *fmin_dev, double tradeoff,
+              int64_t M, int ycols, double *out, bool accumulate);
+int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, int upper, double sign, int64_t M,
+              int ycols, double *out, bool accumulate);
+int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *best_val, int64_t *best_idx1);
+int launch_fill(b7_ctx *c, double *p, int64_t n, double v);

@@ -1,0 +1,180 @@
+// ARD squared-exponential covariance assembly: K(X,X) and K(X*,X).
+//
+// Reference arithmetic replaced (the kernel object itself, gp.kernels.ardse, is in the absent `gp` package;
+// the in-repo statement of its distance is utils.math.pdist):
+//   utils/math.lua:65-111   D = X^2 w (+) (Z^2 w)' - 2 X (Z' .* w),  w = 1/lenscale,  clamp(0, huge) (:106)
+//   K = amp * exp(-D/2)     (+ noise on the diagonal of K(X,X))
+//   mean part of model:predict (scores/expected_improvement.lua:63): mu = m + K(X*,X) alpha
+//
+// Layout: the inner product X (Z' .* w) runs on v_mfma_f64_16x16x4_f64 with the query rows as the A operand
+// and the pre-scaled observations (z .* w, zero-padded to dpad = 4*ceil(d/4)) as B.  A block owns 64 query
+// rows and walks ALL observations in slabs of 64, so it sees whole rows of K(X*,X): the posterior-mean dot
+// product with alpha is accumulated in registers on the way and needs no second pass over K*.
+// Each wave stores 4 rows x 16 consecutive doubles (four full 128-byte lines) per accumulator register.
+// Padding observations carry zss = +inf, which makes their covariance exactly 0.
+#include "b7_internal.h"
+#include "gemm_f64.h"
+
+namespace {
+
+// ---- observation pre-scaling: zsc = z .* w (padded), zss = sum z^2 w --------------------------------------
+__global__ void __launch_bounds__(256) prep_obs_kernel(const double *__restrict__ xobs, const double *__restrict__ ls,
+                                                       double *__restrict__ w, double *__restrict__ zsc,
+                                                       double *__restrict__ zss, int N, int Npad, int d, int dpad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < dpad) w[i] = (i < d) ? 1.0 / ls[i] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
+  if (i >= Npad) return;
+  double s = 0.0;
+  for (int k = 0; k < dpad; ++k) {
+    double z = (i < N && k < d) ? xobs[(int64_t)i * d + k] : 0.0;
+    double wk = (k < d) ? 1.0 / ls[k] : 0.0;
+    zsc[(int64_t)i * dpad + k] = z * wk;
+    s += (z * z) * wk;  // Z_ss = (Z.^2) * inv_ls, :79
+  }
+  zss[i] = (i < N) ? s : __builtin_inf();
+}
+
+// ---- K(X*,X) chunk / K(X,X) -----------------------------------------------------------------------------------
+// xq: query rows, row-major with d columns; rows [row0, row0+rows) of a set with Mtotal rows (rows beyond
+// Mtotal-1 are clamped: they produce values nobody reads).  out: rows x Npad (leading dimension Npad).
+// mu (nullable): mean + K* alpha for ycols == 1.
+constexpr int KQ = 64;  // query rows per block (16 per wave)
+constexpr int KO = 64;  // observation slab
+
+__global__ void __launch_bounds__(256)
+    ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad,
+               const double *__restrict__ w, const double *__restrict__ zsc, const double *__restrict__ zss,
+               const double *__restrict__ alpha, double amp, double meanc, int Npad, double *__restrict__ out,
+               double *__restrict__ mu) {
+  extern __shared__ __align__(16) double sm[];
+  const int stride = dpad + 2;
+  double *sq = sm;                        // KQ x stride
+  double *so = sm + KQ * stride;          // KO x stride
+  double *sxs = so + KO * stride;         // KQ
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t qbase = row0 + (int64_t)blockIdx.x * KQ;
+
+  // stage the query tile (zero-padded columns), one row-major pass
+  for (int e = tid; e < KQ * dpad; e += 256) {
+    int r = e / dpad, k = e - r * dpad;
+    int64_t g = qbase + r;
+    if (g > Mtotal - 1) g = Mtotal - 1;
+    sq[r * stride + k] = (k < d) ? xq[g * d + k] : 0.0;
+  }
+  __syncthreads();
+  if (tid < KQ) {
+    double s = 0.0;
+    for (int k = 0; k < dpad; ++k) {
+      double x = sq[tid * stride + k];
+      s += (x * x) * w[k];  // X_ss = (X.^2) * inv_ls, :78
+    }
+    sxs[tid] = s;
+  }
+
+  double macc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int ksteps = dpad / 4;
+  const double *qa = sq + (wave * 16 + (lane & 15)) * stride + (lane >> 4);
+
+  for (int o0 = 0; o0 < Npad; o0 += KO) {
+    __syncthreads();  // previous slab fully consumed (and sxs visible on the first pass)
+    for (int e = tid; e < KO * dpad; e += 256) {
+      int r = e / dpad, k = e - r * dpad;
+      so[r * stride + k] = zsc[(int64_t)(o0 + r) * dpad + k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KO / 16; ++t) {
+      const double *ob = so + (t * 16 + (lane & 15)) * stride + (lane >> 4);
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < ksteps; ++s) c = mfma_f64(qa[4 * s], ob[4 * s], c);
+      const int col = o0 + t * 16 + (lane & 15);
+      const double zs = zss[col];
+      const double al = alpha ? alpha[col] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qr = wave * 16 + (lane >> 4) + 4 * r;
+        double dist = (c[r] * -2.0 + sxs[qr]) + zs;  // :82 mul(-2):add(X_ss):add(Z_ss')
+        dist = dist < 0.0 ? 0.0 : dist;             // :106 clamp(0, huge)
+        double kv = amp * exp(-0.5 * dist);
+        out[((int64_t)blockIdx.x * KQ + qr) * Npad + col] = kv;
+        macc[r] += kv * al;
+      }
+    }
+  }
+
+  if (mu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = macc[r];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      const int64_t g = qbase + wave * 16 + (lane >> 4) + 4 * r;
+      if ((lane & 15) == 0 && g < Mtotal) mu[g] = meanc + v;
+    }
+  }
+}
+
+// K(X,X) post-pass: padding rows/columns become identity, `diag_add` (noise + jitter) goes on the diagonal.
+__global__ void __launch_bounds__(256)
+    kxx_fix_kernel(double *__restrict__ K, int N, int Npad, double diag_add) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)Npad * Npad) return;
+  int i = (int)(e / Npad), j = (int)(e - (int64_t)i * Npad);
+  if (i >= N || j >= N)
+    K[e] = (i == j) ? 1.0 : 0.0;
+  else if (i == j)
+    K[e] += diag_add;
+}
+
+}  // namespace
+
+int launch_prep_obs(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int d) {
+  int n = c->Npad > c->dpad ? c->Npad : c->dpad;
+  hipLaunchKernelGGL(prep_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, xobs, ls_dev, (double *)c->w.p,
+                     (double *)c->zsc.p, (double *)c->zss.p, N, c->Npad, d, c->dpad);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+static size_t ksx_lds_bytes(int dpad) { return sizeof(double) * ((size_t)(KQ + KO) * (dpad + 2) + KQ); }
+
+// Dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup).
+static int ksx_allow_lds(b7_ctx *c, size_t lds) {
+  if (lds > 160 * 1024) return b7_fail(c, B7_ERR_UNSUPPORTED, "covariance kernel: d too large for LDS");
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return B7_OK;
+}
+
+int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
+               double *mu, int ycols) {
+  PhaseScope ps(c, "ksx");
+  if (rows % KQ) return b7_fail(c, B7_ERR_INVALID, "ksx: rows %lld not a multiple of %d", (long long)rows, KQ);
+  if (ycols != 1 && mu) return b7_fail(c, B7_ERR_UNSUPPORTED, "ksx: fused mean supports ycols == 1");
+  size_t lds = ksx_lds_bytes(c->dpad);
+  B7_TRY(ksx_allow_lds(c, lds));
+  hipLaunchKernelGGL(ksx_kernel, dim3((unsigned)(rows / KQ)), dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad,
+                     (const double *)c->w.p, (const double *)c->zsc.p, (const double *)c->zss.p,
+                     mu ? (const double *)c->alpha.p : nullptr, c->amp, c->mean, c->Npad, ks, mu);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_kxx(b7_ctx *c, double diag_add) {
+  PhaseScope ps(c, "kxx");
+  const int Npad = c->Npad;
+  size_t lds = ksx_lds_bytes(c->dpad);
+  B7_TRY(ksx_allow_lds(c, lds));
+  hipLaunchKernelGGL(ksx_kernel, dim3(Npad / KQ), dim3(256), lds, c->stream, (const double *)c->xobs.p, (int64_t)0,
+                     (int64_t)c->N, c->dfit, c->dpad, (const double *)c->w.p, (const double *)c->zsc.p,
+                     (const double *)c->zss.p, (const double *)nullptr, c->amp, 0.0, Npad, (double *)c->K.p,
+                     (double *)nullptr);
+  B7_HIP(c, hipGetLastError());
+  int64_t total = (int64_t)Npad * Npad;
+  hipLaunchKernelGGL(kxx_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (double *)c->K.p,
+                     c->N, Npad, diag_add);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}

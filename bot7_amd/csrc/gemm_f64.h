@@ -1,0 +1,146 @@
+// fp64 MFMA building blocks for gfx950: v_mfma_f64_16x16x4_f64 through an LDS-staged tile loop.
+//
+// Fragment maps (verified on MI355X by tools/mfma_probe.hip, profiles/r01_mfma_f64_probe.txt):
+//   A operand: lane l holds A[row = l & 15][k = l >> 4]          (one f64)
+//   B operand: lane l holds B[k = l >> 4][col = l & 15]          (one f64)
+//   C/D:       lane l, register r holds D[row = (l >> 4) + 4 r][col = l & 15]
+// Measured issue rate: one 16x16x4 MFMA per 64 cycles per SIMD = 78.6 TFLOP/s chip peak; a single dependent
+// accumulator chain already reaches it, and fp64 VALU FMAs share the same units (they do not add).
+//
+// LDS image of an operand tile: [rows][BK] doubles with row stride BK + 2.  A fragment read is then one
+// ds_read_b64 per lane at (row l&15, k 4s + (l>>4)); with stride = 2 (mod 4) doubles the 32 lanes of each
+// half-wave fall on 32 distinct 8-byte bank pairs (bank = (2*stride*row + 2*kk) mod 64), so it is
+// conflict-free for every BK that is a multiple of 4.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Block-level NT/NN GEMM main loop.
+//   C[m][n] += sum_{k in [kbeg, kend)} A[m][k] * Bop[k][n]
+//   A is row-major [m][k] (leading dimension lda), pointing at the block's first row.
+//   B_KN == false: B is row-major [n][k] (Bop = B^T), pointing at the block's first n-row.
+//   B_KN == true : B is row-major [k][n], pointing at column n0 of row 0.
+// BM x BN block tile, BK-deep LDS stages (double buffered), WM x WN waves, each wave owning a
+// (BM/WM) x (BN/WN) sub-tile as TM x TN MFMA tiles.  All extents are multiples of the tile sizes (callers
+// pad), kbeg/kend multiples of BK.  256 threads.
+template <int BM, int BN, int BK, int WM, int WN, bool B_KN>
+struct GemmF64 {
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int TM = BM / WM / 16;
+  static constexpr int TN = BN / WN / 16;
+  static constexpr int STRIDE = BK + 2;
+  static constexpr int A_CHUNKS = BM * BK / 2;  // 16-byte chunks per stage
+  static constexpr int B_CHUNKS = BN * BK / 2;
+  static constexpr int A_PER_T = A_CHUNKS / THREADS;
+  static constexpr int B_PER_T = B_CHUNKS / THREADS;
+  static constexpr int STAGE_DOUBLES = (BM + BN) * STRIDE;
+  static constexpr int LDS_BYTES = 2 * STAGE_DOUBLES * 8;
+  static_assert(A_CHUNKS % THREADS == 0 && B_CHUNKS % THREADS == 0, "tile/threads mismatch");
+  static_assert(BK % 4 == 0, "BK must be a multiple of the MFMA depth");
+
+  struct Regs {
+    d2_t a[A_PER_T];
+    d2_t b[B_PER_T];
+  };
+
+  __device__ static __forceinline__ void load_global(Regs &r, const double *__restrict__ A, int64_t lda,
+                                                     const double *__restrict__ B, int64_t ldb, int k) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      int c = t + i * THREADS;
+      int row = c / (BK / 2), kc = c % (BK / 2);
+      r.a[i] = *reinterpret_cast<const d2_t *>(A + (int64_t)row * lda + k + 2 * kc);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      int c = t + i * THREADS;
+      if (!B_KN) {
+        int row = c / (BK / 2), kc = c % (BK / 2);
+        r.b[i] = *reinterpret_cast<const d2_t *>(B + (int64_t)row * ldb + k + 2 * kc);
+      } else {
+        int kr = c / (BN / 2), nc = c % (BN / 2);
+        r.b[i] = *reinterpret_cast<const d2_t *>(B + (int64_t)(k + kr) * ldb + 2 * nc);
+      }
+    }
+  }
+
+  __device__ static __forceinline__ void store_lds(const Regs &r, double *__restrict__ sm) {
+    const int t = threadIdx.x;
+    double *sa = sm, *sb = sm + BM * STRIDE;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      int c = t + i * THREADS;
+      int row = c / (BK / 2), kc = c % (BK / 2);
+      *reinterpret_cast<d2_t *>(sa + row * STRIDE + 2 * kc) = r.a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      int c = t + i * THREADS;
+      if (!B_KN) {
+        int row = c / (BK / 2), kc = c % (BK / 2);
+        *reinterpret_cast<d2_t *>(sb + row * STRIDE + 2 * kc) = r.b[i];
+      } else {
+        int kr = c / (BN / 2), nc = c % (BN / 2);
+        sb[(2 * nc) * STRIDE + kr] = r.b[i][0];
+        sb[(2 * nc + 1) * STRIDE + kr] = r.b[i][1];
+      }
+    }
+  }
+
+  __device__ static __forceinline__ void compute_stage(const double *__restrict__ sm, d4_t (&acc)[TM][TN]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const double *sa = sm + (wm * (BM / WM) + (lane & 15)) * STRIDE + (lane >> 4);
+    const double *sb = sm + BM * STRIDE + (wn * (BN / WN) + (lane & 15)) * STRIDE + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      double af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = sa[i * 16 * STRIDE + 4 * s];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = sb[j * 16 * STRIDE + 4 * s];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  // sm: 2 * STAGE_DOUBLES doubles of LDS.  Ends with all waves past the last LDS read (safe to reuse sm
+  // after a __syncthreads() by the caller).
+  __device__ static __forceinline__ void run(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                             int64_t ldb, int kbeg, int kend, d4_t (&acc)[TM][TN],
+                                             double *__restrict__ sm) {
+    if (kbeg >= kend) return;
+    Regs r;
+    load_global(r, A, lda, B, ldb, kbeg);
+    store_lds(r, sm);
+    __syncthreads();
+    int cur = 0;
+    for (int k = kbeg; k < kend; k += BK) {
+      const bool more = (k + BK) < kend;
+      if (more) load_global(r, A, lda, B, ldb, k + BK);
+      compute_stage(sm + cur * STAGE_DOUBLES, acc);
+      if (more) store_lds(r, sm + (cur ^ 1) * STAGE_DOUBLES);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // Output coordinates of accumulator element (i, j, r) of this lane inside the block tile.
+  __device__ static __forceinline__ int out_row(int i, int r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave / WN) * (BM / WM) + i * 16 + (lane >> 4) + 4 * r;
+  }
+  __device__ static __forceinline__ int out_col(int j) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave % WN) * (BN / WN) + j * 16 + (lane & 15);
+  }
+};

@@ -1,0 +1,265 @@
+// GP fit linear algebra: blocked right-looking Cholesky, explicit triangular inverse, alpha = K^-1 (y - m).
+//
+// Reference arithmetic replaced:
+//   utils/math.lua:165      torch.potrf(res, src, 'L')  (LAPACK dpotrf): K = L L'
+//   utils/math.lua:168-202  the pcall/jitter loop around it needs to know THAT a pivot failed: the first
+//                           non-positive pivot is reported (1-based) like dpotrf's info; the retry schedule
+//                           itself runs on the host (api.hip) with the same eps arithmetic
+//   alpha = L^-T L^-1 (Y - mean)  -- first half of gp_regressor:predict (call site
+//                           scores/expected_improvement.lua:63); the op order inside the absent `gp`
+//                           package is unknown, tolerance-checked against oracle/gp.py
+//
+// Structure (all extents padded to multiples of 64/128 by the caller; padding = identity):
+//   per 64-wide panel p:  diag   one workgroup factors the 64x64 diagonal block in LDS and inverts it
+//                         trsm   L21 = A21 * inv(L11)'            (MFMA, one 64x64 tile per workgroup)
+//                         syrk   A22 -= L21 L21'  lower tiles     (MFMA: the trailing update)
+//   inverse of L by recursive doubling over block size s = 64,128,...: for each pair [A 0; B C] of
+//   already-inverted diagonal blocks, X = -inv(C) * (B * inv(A)); two batched MFMA GEMMs per level.
+// The explicit inverse is what lets the posterior variance be one GEMM with a fused column sum of squares
+// (posterior.hip) instead of a triangular solve that would have to store L^-1 K*'.
+#include "b7_internal.h"
+#include "gemm_f64.h"
+
+namespace {
+
+constexpr int NB = B7_PANEL;  // 64
+using G64NT = GemmF64<64, 64, 16, 2, 2, false>;
+using G64NN = GemmF64<64, 64, 16, 2, 2, true>;
+
+// L <- block-lower part of K (upper 64x64 blocks zeroed).
+// `extra` (the jitter of this attempt) is added to the first nreal diagonal entries: src + eps*I.
+__global__ void __launch_bounds__(256)
+    copy_lower_kernel(const double *__restrict__ K, double *__restrict__ L, int n, int nreal, double extra) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  int i = (int)(e / n), j = (int)(e - (int64_t)i * n);
+  double v = ((j / NB) <= (i / NB)) ? K[e] : 0.0;
+  if (i == j && i < nreal) v = v + extra;
+  L[e] = v;
+}
+
+// Factor the diagonal block p in LDS, write L11 (upper zeroed) and inv(L11) (upper zeroed).
+__global__ void __launch_bounds__(256)
+    potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info) {
+  __shared__ double a[NB][NB + 1];
+  __shared__ double x[NB][NB + 1];
+  const int tid = threadIdx.x;
+  double *blk = L + ((int64_t)p * NB) * ld + (int64_t)p * NB;
+  for (int e = tid; e < NB * NB; e += 256) {
+    int i = e >> 6, j = e & 63;
+    a[i][j] = blk[(int64_t)i * ld + j];
+    x[i][j] = 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < NB; ++j) {
+    if (tid == 0) {
+      double piv = a[j][j];
+      if (!(piv > 0.0)) {  // also catches NaN, as dpotrf's "ajj <= 0 or isnan" test
+        if (info[0] == 0) info[0] = p * NB + j + 1;
+        piv = 1.0;  // keep the arithmetic finite; the host discards this attempt
+      }
+      a[j][j] = sqrt(piv);
+    }
+    __syncthreads();
+    const double djj = a[j][j];
+    if (tid > j && tid < NB) a[tid][j] = a[tid][j] / djj;
+    __syncthreads();
+    // rank-1 update of the remaining lower triangle: (i, k) with j < k <= i
+    for (int e = tid; e < NB * NB; e += 256) {
+      int i = e >> 6, k = e & 63;
+      if (k > j && i >= k) a[i][k] -= a[i][j] * a[k][j];
+    }
+    __syncthreads();
+  }
+  // inverse by forward substitution, one column per thread
+  if (tid < NB) {
+    const int cidx = tid;
+    x[cidx][cidx] = 1.0 / a[cidx][cidx];
+    for (int i = cidx + 1; i < NB; ++i) {
+      double s = 0.0;
+      for (int k = cidx; k < i; ++k) s += a[i][k] * x[k][cidx];
+      x[i][cidx] = -s / a[i][i];
+    }
+  }
+  __syncthreads();
+  double *dv = dinv + (int64_t)p * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) {
+    int i = e >> 6, j = e & 63;
+    blk[(int64_t)i * ld + j] = (j <= i) ? a[i][j] : 0.0;
+    dv[e] = (j <= i) ? x[i][j] : 0.0;
+  }
+}
+
+// L21 tile <- A21 tile * inv(L11)'   (in place; the tile is fully read before it is written).
+__global__ void __launch_bounds__(256)
+    potrf_trsm_kernel(double *__restrict__ L, int ld, int p, const double *__restrict__ dinv) {
+  __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
+  double *tile = L + ((int64_t)(p + 1 + blockIdx.x) * NB) * ld + (int64_t)p * NB;
+  d4_t acc[2][2] = {};
+  G64NT::run(tile, ld, dinv + (int64_t)p * NB * NB, NB, 0, NB, acc, sm);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = acc[i][j][r];
+}
+
+// Trailing update: A22[I][J] -= L21[I] L21[J]'  for lower tiles I >= J.
+__global__ void __launch_bounds__(256) potrf_syrk_kernel(double *__restrict__ L, int ld, int p) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
+  const double *a = L + ((int64_t)(p + 1 + I) * NB) * ld + (int64_t)p * NB;
+  const double *b = L + ((int64_t)(p + 1 + J) * NB) * ld + (int64_t)p * NB;
+  double *cblk = L + ((int64_t)(p + 1 + I) * NB) * ld + (int64_t)(p + 1 + J) * NB;
+  d4_t acc[2][2] = {};
+  G64NT::run(a, ld, b, ld, 0, NB, acc, sm);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double *dst = cblk + (int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j);
+        *dst -= acc[i][j][r];
+      }
+}
+
+// Linv <- blockdiag(dinv), zero elsewhere.
+__global__ void __launch_bounds__(256)
+    linv_init_kernel(double *__restrict__ Linv, const double *__restrict__ dinv, int n) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  int i = (int)(e / n), j = (int)(e - (int64_t)i * n);
+  Linv[e] = ((i / NB) == (j / NB)) ? dinv[(int64_t)(i / NB) * NB * NB + (i % NB) * NB + (j % NB)] : 0.0;
+}
+
+// Triangular-inverse level, step 1:  W[C, A] = L[C, A] * Linv[A, A]      (Linv[A,A] lower: k >= j)
+// grid (s/64, s/64, pairs); pair t covers A = [2ts, 2ts+s), C = [2ts+s, min(2ts+2s, n)).
+__global__ void __launch_bounds__(256)
+    trtri_step1_kernel(const double *__restrict__ L, const double *__restrict__ Linv, double *__restrict__ W, int n,
+                       int s) {
+  const int a0 = 2 * blockIdx.z * s, c0 = a0 + s;
+  const int crow = c0 + blockIdx.y * NB;
+  if (crow >= n) return;
+  const int tj = blockIdx.x;
+  __shared__ __align__(16) double sm[2 * G64NN::STAGE_DOUBLES];
+  d4_t acc[2][2] = {};
+  G64NN::run(L + (int64_t)crow * n + a0, n, Linv + (int64_t)a0 * n + a0 + tj * NB, n, tj * NB, s, acc, sm);
+  double *out = W + (int64_t)crow * n + a0 + tj * NB;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(int64_t)G64NN::out_row(i, r) * n + G64NN::out_col(j)] = acc[i][j][r];
+}
+
+// Step 2:  Linv[C, A] = -Linv[C, C] * W[C, A]      (Linv[C,C] lower: k <= i)
+__global__ void __launch_bounds__(256)
+    trtri_step2_kernel(double *__restrict__ Linv, const double *__restrict__ W, int n, int s) {
+  const int a0 = 2 * blockIdx.z * s, c0 = a0 + s;
+  const int ti = blockIdx.y;
+  const int crow = c0 + ti * NB;
+  if (crow >= n) return;
+  const int tj = blockIdx.x;
+  __shared__ __align__(16) double sm[2 * G64NN::STAGE_DOUBLES];
+  d4_t acc[2][2] = {};
+  G64NN::run(Linv + (int64_t)crow * n + c0, n, W + (int64_t)c0 * n + a0 + tj * NB, n, 0, (ti + 1) * NB, acc, sm);
+  double *out = Linv + (int64_t)crow * n + a0 + tj * NB;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(int64_t)G64NN::out_row(i, r) * n + G64NN::out_col(j)] = -acc[i][j][r];
+}
+
+// t = Linv * r  (lower triangular matrix-vector, one wave per row, ycols right-hand sides)
+__global__ void __launch_bounds__(256)
+    trmv_lower_kernel(const double *__restrict__ Linv, const double *__restrict__ r, double *__restrict__ t, int n,
+                      int ycols) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  for (int cidx = 0; cidx < ycols; ++cidx) {
+    double s = 0.0;
+    for (int k = lane; k <= row; k += 64) s += Linv[(int64_t)row * n + k] * r[(int64_t)k * ycols + cidx];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) t[(int64_t)row * ycols + cidx] = s;
+  }
+}
+
+// alpha = Linv' * t : block = 64 columns, 4 waves split the rows, LDS reduce in fixed order.
+__global__ void __launch_bounds__(256)
+    trmv_lower_t_kernel(const double *__restrict__ Linv, const double *__restrict__ t, double *__restrict__ alpha,
+                        int n, int nreal, int ycols) {
+  __shared__ double red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  for (int cidx = 0; cidx < ycols; ++cidx) {
+    double s = 0.0;
+    for (int i = blockIdx.x * 64 + wave; i < n; i += 4)
+      if (i >= col) s += Linv[(int64_t)i * n + col] * t[(int64_t)i * ycols + cidx];
+    red[wave][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (wave == 0) {
+      double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+      alpha[(int64_t)col * ycols + cidx] = (col < nreal) ? v : 0.0;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int launch_potrf(b7_ctx *c, double extra) {
+  PhaseScope ps(c, "potrf");
+  const int n = c->Npad, nb = n / NB;
+  double *L = (double *)c->L.p;
+  int64_t total = (int64_t)n * n;
+  hipLaunchKernelGGL(copy_lower_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double *)c->K.p, L, n, c->N, extra);
+  B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
+  for (int p = 0; p < nb; ++p) {
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, c->stream, L, n, p, (double *)c->dinv.p,
+                       (int *)c->info.p);
+    const int T = nb - p - 1;
+    if (T > 0) {
+      hipLaunchKernelGGL(potrf_trsm_kernel, dim3(T), dim3(256), 0, c->stream, L, n, p, (const double *)c->dinv.p);
+      hipLaunchKernelGGL(potrf_syrk_kernel, dim3(T, T), dim3(256), 0, c->stream, L, n, p);
+    }
+  }
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_trtri(b7_ctx *c) {
+  PhaseScope ps(c, "trtri");
+  const int n = c->Npad;
+  int64_t total = (int64_t)n * n;
+  double *Linv = (double *)c->Linv.p;
+  hipLaunchKernelGGL(linv_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, Linv,
+                     (const double *)c->dinv.p, n);
+  for (int s = NB; s < n; s *= 2) {
+    const int pairs = (n + 2 * s - 1) / (2 * s);
+    dim3 grid(s / NB, s / NB, pairs);
+    hipLaunchKernelGGL(trtri_step1_kernel, grid, dim3(256), 0, c->stream, (const double *)c->L.p,
+                       (const double *)Linv, (double *)c->W.p, n, s);
+    hipLaunchKernelGGL(trtri_step2_kernel, grid, dim3(256), 0, c->stream, Linv, (const double *)c->W.p, n, s);
+  }
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_alpha(b7_ctx *c) {
+  PhaseScope ps(c, "alpha");
+  const int n = c->Npad;
+  // resid holds Y - mean (padded with zeros); alpha is used as the intermediate t = Linv * resid target
+  double *t = (double *)c->W.p;  // W is free after trtri: reuse its first n*ycols entries
+  hipLaunchKernelGGL(trmv_lower_kernel, dim3(n / 4), dim3(256), 0, c->stream, (const double *)c->Linv.p,
+                     (const double *)c->resid.p, t, n, c->ycols);
+  hipLaunchKernelGGL(trmv_lower_t_kernel, dim3(n / 64), dim3(256), 0, c->stream, (const double *)c->Linv.p,
+                     (const double *)t, (double *)c->alpha.p, n, c->N, c->ycols);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}

@@ -1,0 +1,193 @@
+// Acquisition scoring and the arg-max, with the reference's operation order.
+//
+// Reference arithmetic replaced (one rounded op here per Torch tensor op there; contraction is off):
+//   utils/math.lua:261-288  erf   A&S 7.1.26: t = 1/(1+p|x|); Horner in t; 1 - poly*exp(-x^2); sign 2*(x>=0)-1
+//   utils/math.lua:305-312  norm_cdf = (erf(x/sqrt2) + 1) * 0.5       :293-300 norm_pdf = exp(-x^2/2)/sqrt(2pi)
+//   scores/expected_improvement.lua:69-88  sigma = sqrt(var); imprv = (fmin - mu) - xi; z = imprv/sigma;
+//                                          ei = clamp(imprv*Phi(z) + sigma*phi(z), 0, inf); row mean if c > 1
+//   scores/confidence_bound.lua:70-106     LCB = mu - sqrt(var)*k, UCB = mu + sqrt(var)*k; sign flip (:89-93)
+//   bots/bayesopt.lua:69-79                score:add(...) per hyper sample, score:div(nSamples)
+//   bots/bayesopt.lua:96                   score:max(1): first maximum, first NaN wins (TH max)
+// exp/sqrt/division are the correctly-rounded-or-1-ulp ocml double routines; everything else is exact IEEE.
+#pragma clang fp contract(off)
+#include "b7_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double b7_erf(double x) {
+  const double c1 = 0.254829592, c2 = -0.284496736, c3 = 1.421413741, c4 = -1.453152027, c5 = 1.061405429,
+               p = 0.3275911;
+  double t = 1.0 / ((fabs(x) * p) + 1.0);
+  double r = t * c5;
+  r = r + c4;
+  r = r * t;
+  r = r + c3;
+  r = r * t;
+  r = r + c2;
+  r = r * t;
+  r = r + c1;
+  r = r * t;
+  double e = exp((x * x) * -1.0);
+  r = ((r * e) * -1.0) + 1.0;
+  double s = ((x >= 0.0) ? 1.0 : 0.0) * 2.0 + -1.0;
+  return r * s;
+}
+__device__ __forceinline__ double b7_norm_cdf(double z) {
+  double u = z * 0.70710678118654746;  // 1/math.sqrt(2), utils/math.lua:13
+  return (b7_erf(u) + 1.0) * 0.5;
+}
+__device__ __forceinline__ double b7_norm_pdf(double z) {
+  return exp((z * z) * -0.5) * 0.3989422804014327;  // 1/math.sqrt(2*math.pi), utils/math.lua:15
+}
+
+__global__ void __launch_bounds__(256)
+    ei_kernel(const double *__restrict__ mu, const double *__restrict__ var, const double *__restrict__ fmin,
+              double xi, int64_t M, int c, double *__restrict__ out, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
+    double sigma = sqrt(var[j]);
+    double acc = 0.0;
+    for (int k = 0; k < c; ++k) {
+      double imprv = (fmin[k] + (-mu[j * c + k])) + (-xi);
+      double z = imprv / sigma;
+      double ei = (imprv * b7_norm_cdf(z)) + (sigma * b7_norm_pdf(z));
+      ei = (ei < 0.0) ? 0.0 : ei;
+      acc = (c == 1) ? ei : acc + ei;
+    }
+    double v = (c == 1) ? acc : acc / (double)c;
+    out[j] = accumulate ? out[j] + v : v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    cb_kernel(const double *__restrict__ mu, const double *__restrict__ var, double kappa, int upper, double sign,
+              int64_t M, int c, double *__restrict__ out, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
+    double s = sqrt(var[j]) * kappa;
+    double acc = 0.0;
+    for (int k = 0; k < c; ++k) {
+      double v = upper ? (mu[j * c + k] + s) : (mu[j * c + k] + (-s));
+      acc = (c == 1) ? v : acc + v;
+    }
+    double val = (c == 1) ? acc : acc / (double)c;
+    val = (sign > 0.0) ? val : -val;
+    out[j] = accumulate ? out[j] + val : val;
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(double *__restrict__ p, int64_t n, double v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) p[j] = v;
+}
+
+// (value, index) ordering of TH's max: the first NaN wins; otherwise the larger value; ties -> lower index.
+struct Best {
+  double v;
+  int64_t i;
+};
+__device__ __forceinline__ bool better(const Best &a, const Best &b) {  // is a strictly preferred to b
+  if (b.i < 0) return a.i >= 0;
+  if (a.i < 0) return false;
+  const bool an = a.v != a.v, bn = b.v != b.v;
+  if (an || bn) return an && (!bn || a.i < b.i);
+  return (a.v > b.v) || (a.v == b.v && a.i < b.i);
+}
+__device__ __forceinline__ Best wave_best(Best x) {
+  for (int o = 32; o > 0; o >>= 1) {
+    Best y;
+    y.v = __shfl_xor(x.v, o);
+    y.i = __shfl_xor(x.i, o);
+    if (better(y, x)) x = y;
+  }
+  return x;
+}
+__device__ __forceinline__ Best block_best(Best x, Best *sh) {
+  x = wave_best(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = x;
+  __syncthreads();
+  if (wave == 0) {
+    Best y = (lane < (int)(blockDim.x >> 6)) ? sh[lane] : Best{0.0, -1};
+    y = wave_best(y);
+    if (lane == 0) sh[0] = y;
+  }
+  __syncthreads();
+  return sh[0];
+}
+
+// acc[j] /= divisor (score:div), then per-block best.
+__global__ void __launch_bounds__(256)
+    finish_kernel(double *__restrict__ acc, int64_t M, double divisor, Best *__restrict__ part) {
+  __shared__ Best sh[4];
+  Best b{0.0, -1};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
+    double v = acc[j] / divisor;
+    acc[j] = v;
+    Best cnd{v, j};
+    if (better(cnd, b)) b = cnd;
+  }
+  b = block_best(b, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = b;
+}
+
+__global__ void __launch_bounds__(256) argmax_final_kernel(const Best *__restrict__ part, int n, Best *__restrict__ out) {
+  __shared__ Best sh[4];
+  Best b{0.0, -1};
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    if (better(part[j], b)) b = part[j];
+  b = block_best(b, sh);
+  if (threadIdx.x == 0) out[0] = b;
+}
+
+int nblocks(b7_ctx *c, int64_t n) {
+  int64_t b = (n + 255) / 256, cap = (int64_t)c->cus * 8;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+int launch_ei(b7_ctx *c, const double *mu, const double *var, const double *fmin_dev, double tradeoff, int64_t M,
+              int ycols, double *out, bool accumulate) {
+  PhaseScope ps(c, "score");
+  if (M <= 0) return B7_OK;
+  hipLaunchKernelGGL(ei_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, fmin_dev, tradeoff, M, ycols,
+                     out, accumulate ? 1 : 0);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, int upper, double sign, int64_t M,
+              int ycols, double *out, bool accumulate) {
+  PhaseScope ps(c, "score");
+  if (M <= 0) return B7_OK;
+  hipLaunchKernelGGL(cb_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, tradeoff, upper, sign, M,
+                     ycols, out, accumulate ? 1 : 0);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_fill(b7_ctx *c, double *p, int64_t n, double v) {
+  if (n <= 0) return B7_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(nblocks(c, n)), dim3(256), 0, c->stream, p, n, v);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *best_val, int64_t *best_idx1) {
+  PhaseScope ps(c, "argmax");
+  if (M <= 0) return b7_fail(c, B7_ERR_INVALID, "finish: empty score vector");
+  const int nb = nblocks(c, M);
+  B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
+  Best *part = (Best *)c->part.p;
+  hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, c->stream, acc, M, divisor, part);
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb, part + nb);
+  B7_HIP(c, hipGetLastError());
+  Best h;
+  B7_HIP(c, hipMemcpyAsync(&h, part + nb, sizeof(Best), hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (best_val) *best_val = h.v;
+  if (best_idx1) *best_idx1 = h.i + 1;
+  return B7_OK;
+}

@@ -1,0 +1,87 @@
+"""Multi-GPU layout of the scoring path: one process per GPU (torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm), candidates sharded by contiguous row ranges, ONE tiny exchange per nomination.
+
+Candidates are independent given the fitted GP (bots/bayesopt.lua:56-99 scores them elementwise and takes one
+max), so rank r of G owns rows [lo, hi) of the global grid, generates them itself (Sobol is closed-form per
+index; the counter-based random grid likewise), refits the N x N model redundantly (2.9 GFLOP, deterministic,
+cheaper than broadcasting 32 MiB of L) and scores only its shard.  The only data-path communication is the
+arg-max exchange: every rank contributes (value, global 1-based index); RCCL has no MAXLOC, so the pairs are
+summed into a zero-initialised [G, 2] slot buffer (an all-gather in all-reduce clothing, 16 B per rank) and every
+rank picks the winner with TH's max semantics: the first NaN wins, otherwise the largest value, ties to the
+lowest global index -- exactly what score:max(1) (bots/bayesopt.lua:96) returns on the unsharded vector."""
+import numpy as np
+
+
+def shard_range(M, rank, world):
+    """Contiguous, near-equal split of M rows: the first M % world ranks get one extra row."""
+    base, extra = divmod(int(M), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pick_winner(pairs):
+    """pairs: iterable of (value, global_idx1); idx1 <= 0 marks an empty shard.  TH max semantics."""
+    best = None
+    for v, i in pairs:
+        i = int(i)
+        if i <= 0:
+            continue
+        if best is None:
+            best = (v, i)
+            continue
+        bv, bi = best
+        vn, bn = v != v, bv != bv
+        if vn or bn:
+            if vn and (not bn or i < bi):
+                best = (v, i)
+        elif v > bv or (v == bv and i < bi):
+            best = (v, i)
+    if best is None:
+        raise ValueError("every shard is empty")
+    return best
+
+
+def exchange_best(local_val, local_idx1, lo, device=None, group=None):
+    """All ranks learn the global (value, 1-based global index).  local_idx1 is 1-based within the shard that
+    starts at global row `lo` (0-based); pass local_idx1 = 0 for an empty shard.  Indices ride in the f64 slot
+    (exact below 2^53)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if local_idx1 <= 0:
+            raise ValueError("every shard is empty")
+        return local_val, int(lo + local_idx1)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    slots = torch.zeros(world, 2, dtype=torch.float64, device=device)
+    # NaN scores must survive a SUM with zeros from the other ranks: they do (0 + NaN = NaN), and only this
+    # rank writes its own slot.
+    slots[rank, 0] = float(local_val) if local_idx1 > 0 else 0.0
+    slots[rank, 1] = float(lo + local_idx1) if local_idx1 > 0 else 0.0
+    dist.all_reduce(slots, op=dist.ReduceOp.SUM, group=group)
+    s = slots.cpu().numpy()
+    return pick_winner((float(s[r, 0]), int(s[r, 1])) for r in range(world))
+
+
+class ShardedScorer(object):
+    """Rank-local view of a sharded nomination: owns rows [lo, hi) of a global Sobol / counter-random grid on
+    this rank's Context, and turns local (value, index) results into global ones."""
+
+    def __init__(self, ctx, M_global, rank, world):
+        self.ctx, self.M_global, self.rank, self.world = ctx, int(M_global), int(rank), int(world)
+        self.lo, self.hi = shard_range(M_global, rank, world)
+
+    def make_sobol(self, dims, skip=1, mins=None, maxes=None, download=False):
+        return self.ctx.grid_sobol(self.hi - self.lo, dims, skip + self.lo, mins, maxes, download=download)
+
+    def make_random(self, dims, seed=0, mins=None, maxes=None, download=False):
+        return self.ctx.grid_random(self.hi - self.lo, dims, seed, self.lo, mins, maxes, download=download)
+
+    def nominate(self, divisor=1.0, device=None, group=None):
+        """score:div + global score:max(1).  Returns (value, global 1-based index)."""
+        if self.hi > self.lo:
+            v, i, _ = self.ctx.score_finish(divisor, download=False)
+        else:
+            v, i = 0.0, 0
+        return exchange_best(v, i, self.lo, device=device, group=group)

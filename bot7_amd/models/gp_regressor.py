@@ -1,0 +1,118 @@
+"""HIP-backed stand-in for gp.models.gp_regressor with the ardse kernel, GaussianNoise_iso noise model and
+constant mean -- the defaults bots/bayesopt.lua:39-45 selects.
+
+The reference's class lives in the un-vendored `gp` package (models/init.lua:15); what is mirrored here is the
+protocol its callers use:
+    bots/abstract.lua:147-149               model:init(observed, responses)
+    bots/bayesopt.lua:68,74                 model:sample_hypers(X_obs, Y_obs[, nil, nil, true]) -> flat vector
+    bots/bayesopt.lua:75                    model:parse_hypers(vector) -> hyp table
+    scores/expected_improvement.lua:63      model:predict(X_obs, Y_obs, X_hid, hyp, {mean=true, var=true})
+    scores/expected_improvement.lua:57      model:fantasize(nFantasies, X_obs, Y_obs, X_pend, hyp)
+    bots/bayesopt.lua:65                    model:class()
+Everything numerical happens in libbot7hip.so (b7_gp_fit / b7_gp_predict); nothing is computed here.
+
+Hyper-parameter vector layout (ours; the reference's parse_hypers layout is unknowable from its tree):
+    [ lenscale_sq_1 .. lenscale_sq_d, amp, noise, mean ]
+"""
+import numpy as np
+
+from .abstract import abstract
+from .._lib import default_context
+from ..grids.abstract import DeviceGrid
+
+
+class gp_regressor(abstract):
+    title = "bot7.models.gp_regressor"
+
+    def __init__(self, config=None, context=None):
+        self.config = dict(config or {})
+        self.kernel = self.config.get("kernel", "ardse")              # bots/bayesopt.lua:41
+        self.nzModel = self.config.get("nzModel", "GaussianNoise_iso")  # :42
+        self.mean = self.config.get("mean", "constant")               # :43
+        if (self.kernel, self.nzModel, self.mean) != ("ardse", "GaussianNoise_iso", "constant"):
+            raise NotImplementedError("only ardse + GaussianNoise_iso + constant mean are built")
+        self._ctx = context
+        self.hyp = None
+        self.last_fit = None
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    # ---- hyper-parameters -------------------------------------------------------------------------
+    def init(self, X_obs, Y_obs):
+        """model:init (bots/abstract.lua:147-149).  Point initialisation: lenscale_sq = d/8, amp = var(Y),
+        mean = mean(Y), noise = 1e-4*amp (0 when config.noiseless; the jitter schedule then takes over)."""
+        X = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
+        Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
+        d = X.shape[1]
+        amp = float(np.var(Y)) if Y.shape[0] > 1 else 1.0
+        if not amp > 0.0:
+            amp = 1.0
+        noise = 0.0 if self.config.get("noiseless") else 1e-4 * amp
+        self.hyp = self.parse_hypers(np.concatenate([np.full(d, d / 8.0), [amp, noise, float(np.mean(Y))]]))
+        return self.hyp
+
+    def sample_hypers(self, X_obs, Y_obs, _a=None, _b=None, state=None):
+        """Returns the current hyper vector.  The reference draws from the marginal-likelihood posterior with
+        bot7.samplers.slice (host control flow; SURVEY 8f-1 'next' row); every density evaluation that sampler
+        asks for is one b7_gp_fit(..., nll_out) -- see ``nll``."""
+        if self.hyp is None:
+            self.init(X_obs, Y_obs)
+        h = self.hyp
+        return np.concatenate([h["lenscale_sq"], [h["amp"], h["noise"], h["mean"]]])
+
+    @staticmethod
+    def parse_hypers(vec):
+        v = np.asarray(vec, dtype=np.float64).ravel()
+        d = v.size - 3
+        return {"lenscale_sq": v[:d].copy(), "amp": float(v[d]), "noise": float(v[d + 1]), "mean": float(v[d + 2])}
+
+    def nll(self, X_obs, Y_obs, hyp=None):
+        """Negative log marginal likelihood of (X_obs, Y_obs) under hyp: K + Cholesky + log-det + quadratic form
+        on the device -- the unit of work behind the `GP-fit ms` metric."""
+        hyp = hyp or self.hyp
+        out = self.ctx.gp_fit(X_obs, Y_obs, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+        self.last_fit = out
+        return out["nll"]
+
+    # ---- posterior ---------------------------------------------------------------------------------
+    def fit(self, X_obs, Y_obs, hyp=None):
+        hyp = hyp or self.hyp
+        if hyp is None:
+            hyp = self.init(X_obs, Y_obs)
+        self.last_fit = self.ctx.gp_fit(X_obs, Y_obs, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        return self.last_fit
+
+    def _is_resident(self, X1):
+        return isinstance(X1, DeviceGrid) and X1.ctx is self.ctx and X1.shape[0] == self.ctx.grid_shape()[0] \
+            and getattr(X1, "version", -1) == self.ctx.grid_version
+
+    def predict_device(self, X_obs, Y_obs, X_hid, hyp=None):
+        """fit + predict leaving mean/var on the device (for the fused score path).  Uploads X_hid only when it
+        is not the grid already resident on this context."""
+        self.fit(X_obs, Y_obs, hyp)
+        if not self._is_resident(X_hid):
+            self.ctx.grid_upload(np.atleast_2d(np.asarray(X_hid, dtype=np.float64)))
+        self.ctx.gp_predict(download=False)
+
+    def predict(self, X_obs, Y_obs, X_hid, hyp=None, req=None):
+        """model:predict(X0, Y0, X1, hyp, {mean=, var=}) -> {'mean': M x 1, 'var': M}."""
+        self.fit(X_obs, Y_obs, hyp)
+        if self._is_resident(X_hid):
+            mean, var = self.ctx.gp_predict(download=True)
+        else:
+            mean, var = self.ctx.gp_predict_at(np.atleast_2d(np.asarray(X_hid, dtype=np.float64)))
+        req = req or {"mean": True, "var": True}
+        out = {}
+        if req.get("mean"):
+            out["mean"] = mean
+        if req.get("var"):
+            out["var"] = var
+        return out
+
+    def fantasize(self, nFantasies, X_obs, Y_obs, X_pend, hyp=None):
+        raise NotImplementedError("fantasies for pending candidates: SURVEY 8f-2 'next' row (the reference's "
+                                  "driver never passes X_pend, bots/bayesopt.lua:66,76)")

@@ -1,0 +1,169 @@
+/*
+ * bot7hip.h -- C ABI of libbot7hip.so: the MI355X (gfx950) implementation of bot7's GP-posterior +
+ * acquisition-scoring hot path.
+ *
+ * The reference (montyhall/bot7, Lua/Torch7) has no FFI on this path: the "interface" a replacement
+ * must honour is the Lua class protocol of bot7.grids / bot7.models / bot7.scores.  Each entry point
+ * below names the reference method(s) whose arithmetic it replaces (paths relative to the reference
+ * root).  The LuaJIT `ffi.cdef` of exactly these declarations and the three shim classes that call
+ * them are in lua/ and INTEGRATION.md; tests and bench drive the same symbols through ctypes.
+ *
+ * Conventions
+ *   - every function returns int: B7_OK (0) or a negative B7_ERR_*; nothing throws or aborts across the
+ *     boundary; b7_last_error(ctx) gives the message of the last failure on that context;
+ *   - all pointers are HOST pointers to contiguous row-major binary64 (int64_t for indices), owned by the
+ *     caller and only touched during the call; "nullable" outputs may be NULL;
+ *   - device memory is owned by the opaque context; one context = one GPU = one host thread at a time
+ *     (the multi-GPU layout is one process per GPU, each with its own context);
+ *   - calls are synchronous unless stated; row/candidate indices that cross the boundary are 1-BASED
+ *     (Torch convention, bots/bayesopt.lua:96).
+ */
+#ifndef BOT7HIP_H
+#define BOT7HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B7_ABI_VERSION 1
+
+#define B7_OK 0
+#define B7_ERR_INVALID (-1)     /* bad argument (shape, range, NULL) */
+#define B7_ERR_HIP (-2)         /* HIP runtime failure; message holds hipGetErrorString */
+#define B7_ERR_NOMEM (-3)       /* device allocation failed */
+#define B7_ERR_STATE (-4)       /* call order: e.g. predict before fit, score before predict */
+#define B7_ERR_UNSUPPORTED (-5) /* valid in the reference, not built yet (see DESIGN.md "out of scope") */
+#define B7_ERR_RANGE (-6)       /* Sobol: dims >= 40 or index beyond 2^30-2 (grids/sobol.lua:36,317-324) */
+
+typedef struct b7_ctx b7_ctx;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int b7_abi_version(void);
+int b7_create(b7_ctx **out, int device_id);
+void b7_destroy(b7_ctx *ctx);
+const char *b7_last_error(const b7_ctx *ctx);
+/* name_out: >= 64 bytes, nullable. */
+int b7_device_info(b7_ctx *ctx, char *name_out, int *compute_units, int64_t *hbm_bytes);
+int b7_sync(b7_ctx *ctx);
+
+/* Bytes of the K(X*,X) chunk workspace (default 4 GiB); candidates are processed in chunks of
+ * workspace / (8 * Npad) rows.  Must be set before the first predict. */
+int b7_set_workspace(b7_ctx *ctx, int64_t bytes);
+
+/* ---- grids: bot7.grids.sobol / bot7.grids.random ---------------------------------------------- */
+
+/* grids/sobol.lua:58-90 generate + :216-335 i4_sobol.  Row j (1-based) is Sobol point number
+ * j + skip - 1 (Gray-code order, 30 bits), then x*(maxes-mins)+mins as two rounded ops (:79-81);
+ * mins/maxes both NULL = no affine map.  The grid stays resident on the device as THE candidate set;
+ * out_host (nullable, size x dims) receives a copy.  dims must be < 40 (:36).  A rank that owns rows
+ * [lo, hi) of a global grid calls this with size = hi-lo and skip = global_skip + lo. */
+int b7_grid_sobol(b7_ctx *ctx, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
+                  double *out_host);
+
+/* Host-only: the scaled direction numbers V[i][b] = m_(b+1) * 2^(29-b) (i < dims <= 39, b < 30) that
+ * grids/sobol.lua:243-289 builds in self.bank; out has dims*30 entries.  Needs no context and no GPU. */
+int b7_sobol_direction_numbers(int dims, uint32_t *out);
+
+/* grids/random.lua:23-35 with torch.rand replaced by a counter-based generator (Torch's MT19937 stream
+ * is not part of the reference tree): u(row, col) = top 53 bits of splitmix64(seed, row_offset+row, col)
+ * scaled by 2^-53, then the same affine map.  Any dims. */
+int b7_grid_random(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins,
+                   const double *maxes, double *out_host);
+
+/* A caller-made grid (cache.candidates, bots/abstract.lua:30). */
+int b7_grid_upload(b7_ctx *ctx, const double *X_hid, int64_t M, int d);
+int b7_grid_download(b7_ctx *ctx, int64_t row0 /*0-based*/, int64_t rows, double *out_host);
+int b7_grid_shape(b7_ctx *ctx, int64_t *M, int *d);
+
+/* utils/tensor.lua:158-170 remove, as used by steal (:175-193) from bots/abstract.lua:118: stable
+ * deletion of candidate row idx1 (1-based); later rows shift up by one.  row_out (nullable, d) gets the
+ * removed row (what steal appends to `pending`). */
+int b7_grid_remove(b7_ctx *ctx, int64_t idx1, double *row_out);
+
+/* ---- model: gp_regressor + ardse + GaussianNoise_iso + constant mean (bots/bayesopt.lua:40-43) - */
+
+/* Replaces the table model:parse_hypers returns (bots/bayesopt.lua:75).  lenscale_sq[k] is what
+ * utils.math.pdist receives as `lenscale` (it divides squared differences, utils/math.lua:72). */
+typedef struct {
+  const double *lenscale_sq; /* d entries, > 0 */
+  double amp;                /* signal variance sigma_f^2 */
+  double noise;              /* sigma_n^2 added to diag K(X,X) */
+  double mean;               /* constant mean m */
+} b7_hyp;
+
+/* Choices the reference leaves to the absent `gp` package, made explicit (defaults in brackets). */
+typedef struct {
+  double jitter_eps;    /* [1e-8]  utils/math.lua:175 */
+  double jitter_growth; /* [1.1]   utils/math.lua:176 */
+  int var_with_noise;   /* [0] add `noise` to the predictive variance */
+  int var_clamp;        /* [0] clamp variance below at var_min (TH clamp: NaN passes) */
+  double var_min;       /* [0.0] */
+} b7_gp_opts;
+int b7_gp_default_opts(b7_gp_opts *out);
+int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
+
+/* The arithmetic of model:predict's first half (call sites scores/expected_improvement.lua:63,
+ * scores/confidence_bound.lua:63): K = amp*exp(-pdist(X,X,lenscale_sq)/2) + noise*I with the distance of
+ * utils/math.lua:65-111; L = chol(K) with the jitter schedule of utils/math.lua:159-218 (eps <- eps*growth
+ * added to the ORIGINAL diagonal until success, or chol(I) once eps > ||K||_F); alpha = K^-1 (Y - mean).
+ * X_obs N x d, Y_obs N x ycols.  Outputs (all nullable): nll_out[ycols] negative log marginal likelihood,
+ * jitter_used (0 = none, -1 = fell back to chol(I)), info = 1-based first failing pivot of the FIRST
+ * attempt (0 = positive definite). */
+int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp,
+              double *nll_out, double *jitter_used, int *info);
+
+/* Second half of model:predict over the resident candidate grid: mean = m + K(X*,X) alpha (M x ycols),
+ * var = amp - colsumsq(L^-1 K(X*,X)') (M).  Results stay on the device for the score calls; host copies
+ * are optional. */
+int b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);
+
+/* model:predict for arbitrary X1 (M1 x d) that is not the resident grid; does not disturb the grid or the
+ * score accumulator. */
+int b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_host, double *var_host);
+
+/* Inspection (tests): lower Cholesky factor N x N, alpha N x ycols, explicit inverse factor N x N. */
+int b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
+
+/* ---- scores: bot7.scores.expected_improvement / confidence_bound + bayesopt marginalisation ---- */
+
+/* bots/bayesopt.lua:69: score = zeros(M). */
+int b7_score_reset(b7_ctx *ctx);
+/* scores/expected_improvement.lua:69-88 on the last predict, added into the accumulator
+ * (bots/bayesopt.lua:76 score:add).  fmin[ycols] = Y_obs:min(1) (:64); tradeoff = xi (:30). */
+int b7_score_ei(b7_ctx *ctx, const double *fmin, double tradeoff);
+/* scores/confidence_bound.lua:70-106; upper != 0 selects UCB (:96-100) else LCB (:102-106); the result is
+ * val if sign > 0 else -val (:89-93); added into the accumulator. */
+int b7_score_cb(b7_ctx *ctx, double tradeoff, int upper, double sign);
+/* bots/bayesopt.lua:79 score:div(nSamples) then :96 score:max(1): best_val and the 1-based index of the
+ * first maximum (first NaN wins, as TH's max).  divisor = 1 skips nothing: x/1 is exact.
+ * scores_host nullable (M). */
+int b7_score_finish(b7_ctx *ctx, double divisor, double *best_val, int64_t *best_idx1, double *scores_host);
+
+/* EI.compute / conf_bound.compute / max on caller-provided host vectors (M x c mean, M var). */
+int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff,
+                  int64_t M, int c, double *out);
+int b7_cb_compute(b7_ctx *ctx, const double *mean, const double *var, double tradeoff, int upper, double sign,
+                  int64_t M, int c, double *out);
+int b7_argmax(b7_ctx *ctx, const double *scores, int64_t M, double *best_val, int64_t *best_idx1);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+
+/* HIP-event timers on the context's stream (the stream every kernel of this library is launched on). */
+#define B7_MAX_TIMERS 16
+int b7_timer_start(b7_ctx *ctx, int slot);
+int b7_timer_stop(b7_ctx *ctx, int slot);
+int b7_timer_ms(b7_ctx *ctx, int slot, float *ms_out);
+
+/* Per-kernel-phase event timing inside fit/predict/score (off by default: it serialises phases).
+ * Phases: "kxx" "potrf" "trtri" "alpha" "ksx" "post" "score" "argmax" "sobol" "remove".
+ * b7_profile_get returns the summed milliseconds and launch count since the last reset. */
+int b7_profile_enable(b7_ctx *ctx, int on);
+int b7_profile_reset(b7_ctx *ctx);
+int b7_profile_get(b7_ctx *ctx, const char *phase, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOT7HIP_H */

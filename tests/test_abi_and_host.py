@@ -1,0 +1,111 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, fails loudly without
+a GPU, and the host-side mirrors keep the reference's bookkeeping semantics.  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bot7_amd
+from bot7_amd import _lib, dist
+from bot7_amd.utils import tensor as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "bot7hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(b7_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(bot7_amd.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), "libbot7hip.so does not export %s" % name
+    assert sorted(_lib.SYMBOLS) == declared, "python binding list and header disagree"
+    L = _lib.load()
+    assert L.b7_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _has_gpu():
+        pytest.skip("GPU present: the failure path is exercised on the CPU box")
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        bot7_amd.Context(0)
+    assert e.value.code == -2 and "no CPU path" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bot7_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "b7oracle" not in src, f
+
+
+def test_sobol_direction_numbers_match_oracle(orc):
+    for d in (1, 2, 7, 20, 39):
+        assert np.array_equal(_lib.sobol_direction_numbers(d).astype(np.float64), orc.c.sobol_bank(d))
+    with pytest.raises(bot7_amd.Bot7HipError):
+        _lib.sobol_direction_numbers(40)
+
+
+def test_tensor_steal_remove_append(orc):
+    src = np.arange(24.0).reshape(6, 4)
+    res, rest = T.steal(None, src, [3])
+    assert np.array_equal(res, src[2:3]) and np.array_equal(rest, orc.c.remove_row(src, 3))
+    res, rest = T.steal(res, rest, [1])
+    assert np.array_equal(res, src[[2, 0]]) and np.array_equal(rest, src[[1, 3, 4, 5]])
+    assert T.remove(src[:1], [1]) is None                      # utils/tensor.lua:165-169
+    assert T.append(None, np.array([1.0, 2.0])).shape == (1, 2)  # :148-150 row-vector promotion
+
+
+def test_score_and_bot_defaults():
+    ei = bot7_amd.scores.expected_improvement()
+    assert ei.config == {"tradeoff": 0.0, "nFantasies": 100}     # scores/expected_improvement.lua:30-31
+    cb = bot7_amd.scores.confidence_bound()
+    assert cb.config == {"tradeoff": 1.0, "nFantasies": 100, "bound": "lower", "sign": -1.0}  # :31-34
+    assert bot7_amd.scores.confidence_bound({"tradeoff": 0.0}).config["tradeoff"] == 0.0  # Lua: 0 is truthy
+    m = bot7_amd.models.gp_regressor({})
+    assert m.class_() == "bot7.models.gp_regressor"
+    h = m.parse_hypers([0.5, 0.25, 2.0, 1e-3, -1.0])
+    assert list(h["lenscale_sq"]) == [0.5, 0.25] and (h["amp"], h["noise"], h["mean"]) == (2.0, 1e-3, -1.0)
+    with pytest.raises(AssertionError):
+        bot7_amd.grids.sobol({"size": 10, "dims": 40})           # grids/sobol.lua:36
+
+
+def test_shard_ranges_cover_without_overlap():
+    for M, G in [(10, 3), (2 ** 20, 8), (7, 8), (0, 4), (2097152, 8)]:
+        rs = [dist.shard_range(M, r, G) for r in range(G)]
+        assert rs[0][0] == 0 and rs[-1][1] == M and all(rs[i][1] == rs[i + 1][0] for i in range(G - 1))
+        assert max(hi - lo for lo, hi in rs) - min(hi - lo for lo, hi in rs) <= 1
+
+
+def test_pick_winner_th_semantics(orc):
+    rng = np.random.default_rng(0)
+    s = rng.normal(size=1000)
+    s[[100, 700]] = s.max() + 1
+    for G in (1, 2, 3, 8):
+        pairs = []
+        for r in range(G):
+            lo, hi = dist.shard_range(s.size, r, G)
+            i, v = orc.c.argmax_first(s[lo:hi])
+            pairs.append((v, lo + i))
+        assert dist.pick_winner(pairs) == (s[100], 101)
+    s[[900, 300]] = np.nan
+    pairs = []
+    for r in range(4):
+        lo, hi = dist.shard_range(s.size, r, 4)
+        i, v = orc.c.argmax_first(s[lo:hi])
+        pairs.append((v, lo + i))
+    v, i = dist.pick_winner(pairs)
+    assert np.isnan(v) and i == 301 == orc.c.argmax_first(s)[0]
+    assert dist.pick_winner([(1.0, 0), (0.5, 7)]) == (0.5, 7)  # empty shard ignored
