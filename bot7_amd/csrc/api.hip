@@ -287,7 +287,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_HIP(c, hipSetDevice(c->device));
 
   c->fitted = false;
-  invalidate_predictions(c);
+  c->predicted = false;  // the score accumulator survives: marginalisation adds across fits (bots/bayesopt.lua:73-78)
   c->N = N;
   c->Npad = (int)round_up(N, B7_NPAD);
   c->dfit = d;

@@ -1,0 +1,43 @@
+--[[
+Drop-in for bot7.grids.sobol (grids/sobol.lua) backed by b7_grid_sobol.
+Register:  bot7.grids.sobol = require('bot7hip.grids_sobol_hip')   (or select with config.grid.type = 'sobol_hip')
+Same constructor asserts (grids/sobol.lua:35-36) and the same generate(config) contract (:58-90); the grid also
+stays resident on the GPU as the candidate set.
+--]]
+local ffi = require('ffi')
+local hip = require('bot7hip.bot7hip_ffi')
+
+local title  = 'bot7.grids.sobol_hip'
+local parent = 'bot7.grids.abstract'
+local grid, parent = torch.class(title, parent)
+
+function grid:__init(config)
+  parent.__init(self)
+  local C = config or {}
+  C.max_dims = C.max_dims or 40
+  C.log_max  = C.log_max or 30
+  assert(C.size)
+  assert(C.dims and C.dims < C.max_dims)
+  self.config = C
+end
+
+function grid:generate(config)
+  local config = config or self.config
+  local skip   = config.skip or 1
+  local out    = torch.DoubleTensor(config.size, config.dims)
+  local both   = config.mins and config.maxes
+  hip.check(hip.C.b7_grid_sobol(hip.ctx, config.size, config.dims, skip,
+            both and hip.ptr(config.mins) or nil, both and hip.ptr(config.maxes) or nil, torch.data(out)))
+  hip.grid_version = hip.grid_version + 1
+  if not both and config.mins then          -- grids/sobol.lua:82-83 (host side, rare)
+    out:add(torch.add(config.mins, out:min(1)[1]):expandAs(out))
+    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
+  elseif not both and config.maxes then     -- :84-85
+    out:cmul(torch.cdiv(config.maxes, out:max(1)[1]):expandAs(out))
+    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
+  end
+  hip.resident = {ptr = torch.data(out), rows = out:size(1), version = hip.grid_version}
+  return out
+end
+
+return grid
