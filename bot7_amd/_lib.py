@@ -19,7 +19,7 @@ ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
-    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_download",
+    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_download",
     "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
@@ -81,6 +81,7 @@ def load():
         "b7_gp_default_opts": (i32, [C.POINTER(GpOpts)]),
         "b7_gp_set_opts": (i32, [vp, C.POINTER(GpOpts)]),
         "b7_gp_fit": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(Hyp), vp, C.POINTER(dbl), C.POINTER(i32)]),
+        "b7_chol": (i32, [vp, vp, i32, vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_gp_predict": (i32, [vp, vp, vp]),
         "b7_gp_predict_at": (i32, [vp, vp, i64, vp, vp]),
         "b7_gp_download": (i32, [vp, vp, vp, vp]),
@@ -236,6 +237,15 @@ class Context(object):
         self._ck(self._L.b7_gp_fit(self._h, _ptr(X), _ptr(Y), N, d, Y.shape[1], C.byref(hyp), _ptr(nll),
                                    C.byref(jit), C.byref(info)))
         return {"nll": nll, "jitter": jit.value, "info": info.value}
+
+    def chol(self, src):
+        """utils.math.chol(src, 'L') with the jitter schedule; returns (L, jitter_used, info_first)."""
+        A = _f64(src)
+        n = A.shape[0]
+        res = np.empty((n, n), dtype=np.float64)
+        jit, info = C.c_double(), C.c_int()
+        self._ck(self._L.b7_chol(self._h, _ptr(A), n, _ptr(res), C.byref(jit), C.byref(info)))
+        return res, jit.value, info.value
 
     def gp_predict(self, download=True):
         M, _ = self.grid_shape()

@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "b7_internal.h"
@@ -96,6 +97,8 @@ int b7_create(b7_ctx **out, int device_id) {
   c->device = device_id;
   c->cus = prop.multiProcessorCount;
   b7_gp_default_opts(&c->opts);
+  if (const char *pv = getenv("B7_POST_VARIANT")) c->post_variant = atoi(pv);
+  if (const char *pv = getenv("B7_KSX_ABLATE")) c->ksx_ablate = atoi(pv);
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->pev[0]);
   if (e == hipSuccess) e = hipEventCreate(&c->pev[1]);
@@ -273,6 +276,7 @@ int b7_gp_set_opts(b7_ctx *c, const b7_gp_opts *o) {
 
 // One factorisation attempt of K + extra*I; returns dpotrf-style info through *info.
 static int try_factor(b7_ctx *c, double extra, int *info);
+static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out);
 
 int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,
               double *nll_out, double *jitter_used, int *info_out) {
@@ -320,42 +324,9 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
   B7_TRY(launch_kxx(c, hyp->noise));
 
-  // utils/math.lua:159-218: plain attempt, then the growing-jitter retries on the ORIGINAL matrix.
-  int info = 0;
-  B7_TRY(try_factor(c, 0.0, &info));
-  const int info_first = info;
+  int info_first = 0;
   double jitter = 0.0;
-  if (info != 0) {
-    // max_eps = src:norm() (Frobenius) of the N x N matrix that was handed to chol (:174)
-    std::vector<double> Kh((size_t)N * N);
-    B7_HIP(c, hipMemcpy2D(Kh.data(), sizeof(double) * N, c->K.p, sizeof(double) * np, sizeof(double) * N, N,
-                          hipMemcpyDeviceToHost));
-    double fro = 0.0;
-    for (double v : Kh) fro += v * v;
-    const double max_eps = sqrt(fro);
-    if (max_eps != max_eps)  // the reference's while-loop never ends here (eps > NaN is false); fail instead
-      return b7_fail(c, B7_ERR_INVALID, "gp_fit: K(X,X) contains NaN (check X_obs and the hyper-parameters)");
-    double eps = c->opts.jitter_eps;
-    for (;;) {
-      if (eps > max_eps) {  // :184-186 chol(I)
-        jitter = -1.0;
-        std::vector<double> eye(np * np, 0.0);
-        for (size_t i = 0; i < np; ++i) eye[i * np + i] = 1.0;
-        B7_HIP(c, hipMemcpy(c->L.p, eye.data(), nn, hipMemcpyHostToDevice));
-        std::vector<double> di(np * B7_PANEL, 0.0);
-        for (size_t b = 0; b < np / B7_PANEL; ++b)
-          for (int i = 0; i < B7_PANEL; ++i) di[b * B7_PANEL * B7_PANEL + i * B7_PANEL + i] = 1.0;
-        B7_HIP(c, hipMemcpy(c->dinv.p, di.data(), sizeof(double) * np * B7_PANEL, hipMemcpyHostToDevice));
-        break;
-      }
-      eps = eps * c->opts.jitter_growth;  // :188
-      B7_TRY(try_factor(c, eps, &info));
-      if (info == 0) {
-        jitter = eps;
-        break;
-      }
-    }
-  }
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first));
   B7_TRY(launch_trtri(c));
   B7_TRY(launch_alpha(c));
   B7_HIP(c, hipStreamSynchronize(c->stream));
@@ -388,6 +359,51 @@ static int try_factor(b7_ctx *c, double extra, int *info) {
   return B7_OK;
 }
 
+// utils/math.lua:159-218 on c->K (N x N inside Npad x Npad): plain attempt, then the growing-jitter retries on
+// the ORIGINAL matrix; leaves L and dinv on the device.
+static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out) {
+  const int N = c->N;
+  const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
+  int info = 0;
+  B7_TRY(try_factor(c, 0.0, &info));
+  *info_first_out = info;
+  double jitter = 0.0;
+  if (info != 0) {
+    // max_eps = src:norm() (Frobenius) of the N x N matrix that was handed to chol (:174)
+    std::vector<double> Kh((size_t)N * N);
+    B7_HIP(c, hipMemcpy2D(Kh.data(), sizeof(double) * N, c->K.p, sizeof(double) * np, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+    double fro = 0.0;
+    for (double v : Kh) fro += v * v;
+    const double max_eps = sqrt(fro);
+    if (max_eps != max_eps)  // the reference's while-loop never ends here (eps > NaN is false); fail instead
+      return b7_fail(c, B7_ERR_INVALID, "chol: the matrix contains NaN (check X_obs and the hyper-parameters)");
+    double eps = c->opts.jitter_eps;
+    for (;;) {
+      if (eps > max_eps) {  // :184-186 chol(I)
+        jitter = -1.0;
+        std::vector<double> eye(np * np, 0.0);
+        for (size_t i = 0; i < np; ++i) eye[i * np + i] = 1.0;
+        B7_HIP(c, hipMemcpy(c->L.p, eye.data(), nn, hipMemcpyHostToDevice));
+        std::vector<double> di(np * B7_PANEL, 0.0);
+        for (size_t b = 0; b < np / B7_PANEL; ++b)
+          for (int i = 0; i < B7_PANEL; ++i) di[b * B7_PANEL * B7_PANEL + i * B7_PANEL + i] = 1.0;
+        B7_HIP(c, hipMemcpy(c->dinv.p, di.data(), sizeof(double) * np * B7_PANEL, hipMemcpyHostToDevice));
+        break;
+      }
+      eps = eps * c->opts.jitter_growth;  // :188
+      B7_TRY(try_factor(c, eps, &info));
+      if (info == 0) {
+        jitter = eps;
+        break;
+      }
+    }
+  }
+  *jitter_out = jitter;
+  return B7_OK;
+}
+
+
 extern "C" {
 
 static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, double *var) {
@@ -403,6 +419,38 @@ static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, doub
     B7_TRY(launch_ksx(c, xq, row0, rows, M, c->dfit, (double *)c->ks.p, mu, c->ycols));
     B7_TRY(launch_post(c, (const double *)c->ks.p, row0, rows, M, var));
   }
+  return B7_OK;
+}
+
+int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_used, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!src || !res || n < 1) return b7_fail(c, B7_ERR_INVALID, "chol: bad arguments");
+  B7_HIP(c, hipSetDevice(c->device));
+  c->fitted = false;
+  c->predicted = false;
+  c->N = n;
+  c->Npad = (int)round_up(n, B7_NPAD);
+  const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
+  B7_TRY(b7_ensure(c, c->K, nn));
+  B7_TRY(b7_ensure(c, c->L, nn));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
+  std::vector<double> Kp(np * np, 0.0);
+  for (size_t i = 0; i < np; ++i) {
+    if (i < (size_t)n)
+      memcpy(&Kp[i * np], src + i * (size_t)n, sizeof(double) * n);
+    else
+      Kp[i * np + i] = 1.0;
+  }
+  B7_HIP(c, hipMemcpy(c->K.p, Kp.data(), nn, hipMemcpyHostToDevice));
+  int info_first = 0;
+  double jitter = 0.0;
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  B7_HIP(c, hipMemcpy2D(res, sizeof(double) * n, c->L.p, sizeof(double) * np, sizeof(double) * n, n,
+                        hipMemcpyDeviceToHost));
+  if (jitter_used) *jitter_used = jitter;
+  if (info_out) *info_out = info_first;
   return B7_OK;
 }
 

@@ -12,7 +12,7 @@
 // Tile constants.  Every matrix dimension that a GEMM-class kernel sees is padded to these.
 constexpr int B7_NPAD = 128;  // observations padded to a multiple of this (post kernel's n-tile)
 constexpr int B7_PANEL = 64;  // Cholesky panel width / small-GEMM tile
-constexpr int B7_MROWS = 128; // candidate rows per post-kernel block; chunk rows are multiples of this
+constexpr int B7_MROWS = 256; // chunk rows are multiples of this (largest candidates-per-block of any post variant)
 constexpr int B7_MAX_D = 128; // LDS budget of the covariance kernel: 128 rows x (dpad+2) doubles <= 160 KiB
 
 struct DevBuf {
@@ -65,6 +65,8 @@ struct b7_ctx {
   bool acc_valid = false;
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
+  int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
+  int post_variant = 7;  // tile/occupancy variant of post_kernel (B7_POST_VARIANT overrides; see posterior.hip)
   DevBuf part;   // argmax partials (value, index)
   DevBuf scratch; // misc (fmin upload, results)
   DevBuf tmpgrid; // predict_at temporary grid

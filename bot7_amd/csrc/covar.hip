@@ -41,6 +41,8 @@ __global__ void __launch_bounds__(256) prep_obs_kernel(const double *__restrict_
 constexpr int KQ = 64;  // query rows per block (16 per wave)
 constexpr int KO = 64;  // observation slab
 
+// ABLATE (diagnostic builds only, B7_KSX_ABLATE): 0 = product; 1 = no stores; 2 = no exp; 3 = no MFMA.
+template <int ABLATE>
 __global__ void __launch_bounds__(256)
     ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad,
                const double *__restrict__ w, const double *__restrict__ zsc, const double *__restrict__ zss,
@@ -86,7 +88,10 @@ __global__ void __launch_bounds__(256)
     for (int t = 0; t < KO / 16; ++t) {
       const double *ob = so + (t * 16 + (lane & 15)) * stride + (lane >> 4);
       d4_t c = {0.0, 0.0, 0.0, 0.0};
-      for (int s = 0; s < ksteps; ++s) c = mfma_f64(qa[4 * s], ob[4 * s], c);
+      if (ABLATE != 3)
+        for (int s = 0; s < ksteps; ++s) c = mfma_f64(qa[4 * s], ob[4 * s], c);
+      else
+        c[0] = c[1] = c[2] = c[3] = qa[0] * ob[0];
       const int col = o0 + t * 16 + (lane & 15);
       const double zs = zss[col];
       const double al = alpha ? alpha[col] : 0.0;
@@ -95,14 +100,14 @@ __global__ void __launch_bounds__(256)
         const int qr = wave * 16 + (lane >> 4) + 4 * r;
         double dist = (c[r] * -2.0 + sxs[qr]) + zs;  // :82 mul(-2):add(X_ss):add(Z_ss')
         dist = dist < 0.0 ? 0.0 : dist;             // :106 clamp(0, huge)
-        double kv = amp * exp(-0.5 * dist);
-        out[((int64_t)blockIdx.x * KQ + qr) * Npad + col] = kv;
+        double kv = (ABLATE == 2) ? amp * (-0.5 * dist) : amp * exp(-0.5 * dist);
+        if (ABLATE != 1) out[((int64_t)blockIdx.x * KQ + qr) * Npad + col] = kv;
         macc[r] += kv * al;
       }
     }
   }
 
-  if (mu) {
+  if (mu || ABLATE == 1) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double v = macc[r];
@@ -111,7 +116,8 @@ __global__ void __launch_bounds__(256)
       v += __shfl_xor(v, 4);
       v += __shfl_xor(v, 8);
       const int64_t g = qbase + wave * 16 + (lane >> 4) + 4 * r;
-      if ((lane & 15) == 0 && g < Mtotal) mu[g] = meanc + v;
+      if ((lane & 15) == 0 && g < Mtotal && mu) mu[g] = meanc + v;
+      if (ABLATE == 1 && !mu && v == 1.2345e300) out[0] = v;  // keeps the arithmetic alive without stores
     }
   }
 }
@@ -143,7 +149,13 @@ static size_t ksx_lds_bytes(int dpad) { return sizeof(double) * ((size_t)(KQ + K
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup).
 static int ksx_allow_lds(b7_ctx *c, size_t lds) {
   if (lds > 160 * 1024) return b7_fail(c, B7_ERR_UNSUPPORTED, "covariance kernel: d too large for LDS");
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel),
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return B7_OK;
 }
@@ -155,7 +167,11 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
   if (ycols != 1 && mu) return b7_fail(c, B7_ERR_UNSUPPORTED, "ksx: fused mean supports ycols == 1");
   size_t lds = ksx_lds_bytes(c->dpad);
   B7_TRY(ksx_allow_lds(c, lds));
-  hipLaunchKernelGGL(ksx_kernel, dim3((unsigned)(rows / KQ)), dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad,
+  auto kern = ksx_kernel<0>;
+  if (c->ksx_ablate == 1) kern = ksx_kernel<1>;
+  if (c->ksx_ablate == 2) kern = ksx_kernel<2>;
+  if (c->ksx_ablate == 3) kern = ksx_kernel<3>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / KQ)), dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad,
                      (const double *)c->w.p, (const double *)c->zsc.p, (const double *)c->zss.p,
                      mu ? (const double *)c->alpha.p : nullptr, c->amp, c->mean, c->Npad, ks, mu);
   B7_HIP(c, hipGetLastError());
@@ -167,7 +183,7 @@ int launch_kxx(b7_ctx *c, double diag_add) {
   const int Npad = c->Npad;
   size_t lds = ksx_lds_bytes(c->dpad);
   B7_TRY(ksx_allow_lds(c, lds));
-  hipLaunchKernelGGL(ksx_kernel, dim3(Npad / KQ), dim3(256), lds, c->stream, (const double *)c->xobs.p, (int64_t)0,
+  hipLaunchKernelGGL(ksx_kernel<0>, dim3(Npad / KQ), dim3(256), lds, c->stream, (const double *)c->xobs.p, (int64_t)0,
                      (int64_t)c->N, c->dfit, c->dpad, (const double *)c->w.p, (const double *)c->zsc.p,
                      (const double *)c->zss.p, (const double *)nullptr, c->amp, 0.0, Npad, (double *)c->K.p,
                      (double *)nullptr);

@@ -7,10 +7,14 @@
 // Measured issue rate: one 16x16x4 MFMA per 64 cycles per SIMD = 78.6 TFLOP/s chip peak; a single dependent
 // accumulator chain already reaches it, and fp64 VALU FMAs share the same units (they do not add).
 //
-// LDS image of an operand tile: [rows][BK] doubles with row stride BK + 2.  A fragment read is then one
-// ds_read_b64 per lane at (row l&15, k 4s + (l>>4)); with stride = 2 (mod 4) doubles the 32 lanes of each
-// half-wave fall on 32 distinct 8-byte bank pairs (bank = (2*stride*row + 2*kk) mod 64), so it is
-// conflict-free for every BK that is a multiple of 4.
+// LDS image of an operand tile: [rows][BK] doubles with row stride BK + PAD.  A fragment read is one 8-byte
+// read per lane at (row l&15, k 4s + (l>>4)).  hipcc fuses the reads of k-steps s and s+1 into ds_read2_b64,
+// which is serviced in 16-lane groups over 32 four-byte banks: 16 rows at one k hit distinct bank pairs only when
+// the stride is ODD (2*stride*row mod 32 must take 16 values); measured on the PAD = 2 image: 40 % of all LDS
+// cycles were conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r01b_*).  An odd stride is
+// also conflict-free for plain ds_read_b64 (64 banks, 32-lane groups: (34 r + 2 kk) mod 64 are all distinct).
+// The price is that rows are only 8-byte aligned, so staging stores are ds_write_b64 pairs.
+// PAD = 2 (stride = 2 mod 4) is kept for the small-GEMM users: conflict-free for ds_read_b64 only.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,12 +33,13 @@ __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c) {
 // BM x BN block tile, BK-deep LDS stages (double buffered), WM x WN waves, each wave owning a
 // (BM/WM) x (BN/WN) sub-tile as TM x TN MFMA tiles.  All extents are multiples of the tile sizes (callers
 // pad), kbeg/kend multiples of BK.  256 threads.
-template <int BM, int BN, int BK, int WM, int WN, bool B_KN>
+template <int BM, int BN, int BK, int WM, int WN, bool B_KN, int PAD = 2>
 struct GemmF64 {
   static constexpr int THREADS = 64 * WM * WN;
   static constexpr int TM = BM / WM / 16;
   static constexpr int TN = BN / WN / 16;
-  static constexpr int STRIDE = BK + 2;
+  static constexpr int STRIDE = BK + PAD;
+  static constexpr bool ALIGNED16 = (STRIDE % 2) == 0;
   static constexpr int A_CHUNKS = BM * BK / 2;  // 16-byte chunks per stage
   static constexpr int B_CHUNKS = BN * BK / 2;
   static constexpr int A_PER_T = A_CHUNKS / THREADS;
@@ -78,18 +83,55 @@ struct GemmF64 {
     for (int i = 0; i < A_PER_T; ++i) {
       int c = t + i * THREADS;
       int row = c / (BK / 2), kc = c % (BK / 2);
-      *reinterpret_cast<d2_t *>(sa + row * STRIDE + 2 * kc) = r.a[i];
+      if (ALIGNED16) {
+        *reinterpret_cast<d2_t *>(sa + row * STRIDE + 2 * kc) = r.a[i];
+      } else {
+        sa[row * STRIDE + 2 * kc] = r.a[i][0];
+        sa[row * STRIDE + 2 * kc + 1] = r.a[i][1];
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
       int c = t + i * THREADS;
       if (!B_KN) {
         int row = c / (BK / 2), kc = c % (BK / 2);
-        *reinterpret_cast<d2_t *>(sb + row * STRIDE + 2 * kc) = r.b[i];
+        if (ALIGNED16) {
+          *reinterpret_cast<d2_t *>(sb + row * STRIDE + 2 * kc) = r.b[i];
+        } else {
+          sb[row * STRIDE + 2 * kc] = r.b[i][0];
+          sb[row * STRIDE + 2 * kc + 1] = r.b[i][1];
+        }
       } else {
         int kr = c / (BN / 2), nc = c % (BN / 2);
         sb[(2 * nc) * STRIDE + kr] = r.b[i][0];
         sb[(2 * nc + 1) * STRIDE + kr] = r.b[i][1];
+      }
+    }
+  }
+
+  // Same, for a stage that lies inside the diagonal block of a lower-triangular A: krel = offset of the stage's
+  // first k inside that block.  A[row][k] = 0 for k > row, so the 16-row strip i of this wave contributes to
+  // k-step s only while krel + 4 s <= (last row of the strip); the branch is wave-uniform.
+  __device__ static __forceinline__ void compute_stage_tri(const double *__restrict__ sm, d4_t (&acc)[TM][TN],
+                                                           int krel) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the skips become s_cbranch
+    const int wm = wave / WN, wn = wave % WN;
+    const double *sa = sm + (wm * (BM / WM) + (lane & 15)) * STRIDE + (lane >> 4);
+    const double *sb = sm + BM * STRIDE + (wn * (BN / WN) + (lane & 15)) * STRIDE + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      const int kk = krel + 4 * s;
+      if (kk > wm * (BM / WM) + 16 * (TM - 1) + 15) continue;  // nothing left for this wave
+      double bf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = sb[j * 16 * STRIDE + 4 * s];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (kk > wm * (BM / WM) + 16 * i + 15) continue;
+        const double af = sa[i * 16 * STRIDE + 4 * s];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f64(af, bf[j], acc[i][j]);
       }
     }
   }
@@ -115,6 +157,9 @@ struct GemmF64 {
 
   // sm: 2 * STAGE_DOUBLES doubles of LDS.  Ends with all waves past the last LDS read (safe to reuse sm
   // after a __syncthreads() by the caller).
+  // TRI: A's block-row is the diagonal block-row of a lower-triangular matrix whose diagonal block occupies
+  // the last BM columns [kend - BM, kend): structural zeros there are skipped (compute_stage_tri).
+  template <bool TRI = false>
   __device__ static __forceinline__ void run(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
                                              int64_t ldb, int kbeg, int kend, d4_t (&acc)[TM][TN],
                                              double *__restrict__ sm) {
@@ -124,13 +169,24 @@ struct GemmF64 {
     store_lds(r, sm);
     __syncthreads();
     int cur = 0;
-    for (int k = kbeg; k < kend; k += BK) {
+    const int ksplit = TRI ? (kend - BM > kbeg ? kend - BM : kbeg) : kend;
+    for (int k = kbeg; k < ksplit; k += BK) {
       const bool more = (k + BK) < kend;
       if (more) load_global(r, A, lda, B, ldb, k + BK);
       compute_stage(sm + cur * STAGE_DOUBLES, acc);
       if (more) store_lds(r, sm + (cur ^ 1) * STAGE_DOUBLES);
       __syncthreads();
       cur ^= 1;
+    }
+    if (TRI) {
+      for (int k = ksplit; k < kend; k += BK) {
+        const bool more = (k + BK) < kend;
+        if (more) load_global(r, A, lda, B, ldb, k + BK);
+        compute_stage_tri(sm + cur * STAGE_DOUBLES, acc, k - (kend - BM));
+        if (more) store_lds(r, sm + (cur ^ 1) * STAGE_DOUBLES);
+        __syncthreads();
+        cur ^= 1;
+      }
     }
   }
 

@@ -11,6 +11,11 @@
 // The summation order is fixed (n-tiles ascending, then a fixed shuffle/LDS tree), so results are bitwise
 // reproducible run to run -- the arg-max downstream depends on that.
 //
+// Variants (A/B in one process on MI355X, N = 2048, 262144 candidates, tools/post_ab.py; all bitwise identical):
+//   0: 128x128 tile, 1 wave/SIMD 44.6 TF | 1: 2 blocks/CU 59.2 | 4: + odd LDS stride 59.7 | 5: + zero-strip skip
+//   61.3 | 6: both 61.6 | 7 (default): both on a 128(n) x 256(cand) tile, 8 waves 63.6 TF = 81 % of 78.6.
+// PMC on variant 1: MFMA pipe 87 % busy, effective clock 2.03 GHz (DVFS) -> 66.7 TF is the ceiling at that clock.
+//
 // Algorithmic work per launch: rows * Npad^2 flops (triangle exploited), bytes: the K* chunk is read
 // (t+1)/T-weighted ~ (T+1)/2 times from L2/MALL/HBM (T = Npad/128 n-tiles), Linv once per block from L2.
 #include "b7_internal.h"
@@ -18,20 +23,22 @@
 
 namespace {
 
-using GP = GemmF64<128, 128, 16, 2, 2, false>;
-
-__global__ void __launch_bounds__(256)
+// BM = rows of L^-1 per n-tile, BN = candidates per block, WM x WN waves of 64x64 accumulators each.
+template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI>
+__global__ void __launch_bounds__(64 * WM * WN, MINW)
     post_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0,
                 int64_t Mtotal, double amp, double var_add, int clamp, double var_min, double *__restrict__ var) {
+  using GP = GemmF64<BM, BN, 16, WM, WN, false, PAD>;
+  static_assert(GP::TM == 4 && GP::TN == 4, "64x64 per wave");
   extern __shared__ __align__(16) double sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double *B = ks + (int64_t)blockIdx.x * 128 * Npad;  // this block's 128 candidate rows of K*
+  const double *B = ks + (int64_t)blockIdx.x * BN * Npad;  // this block's BN candidate rows of K*
   double colss[GP::TN] = {};
 
-  const int ntiles = Npad / 128;
+  const int ntiles = Npad / BM;
   for (int t = 0; t < ntiles; ++t) {
     d4_t acc[GP::TM][GP::TN] = {};
-    GP::run(Linv + (int64_t)t * 128 * Npad, Npad, B, Npad, 0, (t + 1) * 128, acc, sm);
+    GP::template run<TRI>(Linv + (int64_t)t * BM * Npad, Npad, B, Npad, 0, (t + 1) * BM, acc, sm);
 #pragma unroll
     for (int j = 0; j < GP::TN; ++j) {
       double s = 0.0;
@@ -43,20 +50,23 @@ __global__ void __launch_bounds__(256)
     }
   }
 
-  // lanes l, l^16, l^32, l^48 hold partial sums of the same candidate column
-  double *red = sm;  // [2 (wm)][128]; GP::run ended with a barrier, LDS is free
+  // lanes l, l^16, l^32, l^48 hold partial sums of the same candidate column; then the WM row-waves
+  double *red = sm;  // [WM][BN]; GP::run ended with a barrier, LDS is free
+  const int wm = wave / WN, wn = wave % WN;
 #pragma unroll
   for (int j = 0; j < GP::TN; ++j) {
     double v = colss[j];
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (lane < 16) red[(wave / 2) * 128 + (wave % 2) * 64 + j * 16 + lane] = v;
+    if (lane < 16) red[wm * BN + wn * 64 + j * 16 + lane] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 128) {
-    const int64_t g = row0 + (int64_t)blockIdx.x * 128 + threadIdx.x;
+  if (threadIdx.x < BN) {
+    const int64_t g = row0 + (int64_t)blockIdx.x * BN + threadIdx.x;
     if (g < Mtotal) {
-      double ss = red[threadIdx.x] + red[128 + threadIdx.x];
+      double ss = red[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < WM; ++w) ss += red[w * BN + threadIdx.x];
       double v = (amp - ss) + var_add;
       if (clamp) v = (v < var_min) ? var_min : v;  // TH clamp: NaN passes through
       var[g] = v;
@@ -64,17 +74,34 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI>
+int launch_post_variant(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
+  using GP = GemmF64<BM, BN, 16, WM, WN, false, PAD>;
+  auto kern = post_kernel<BM, BN, WM, WN, MINW, PAD, TRI>;
+  const int lds = GP::LDS_BYTES;
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / BN)), dim3(64 * WM * WN), lds, c->stream, (const double *)c->Linv.p,
+                     ks, c->Npad, row0, Mtotal, c->amp, c->opts.var_with_noise ? c->noise : 0.0, c->opts.var_clamp,
+                     c->opts.var_min, var);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
 }  // namespace
 
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
   PhaseScope ps(c, "post");
-  if (rows % 128) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of 128", (long long)rows);
-  const int lds = GP::LDS_BYTES;
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(post_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(post_kernel, dim3((unsigned)(rows / 128)), dim3(256), lds, c->stream,
-                     (const double *)c->Linv.p, ks, c->Npad, row0, Mtotal, c->amp,
-                     c->opts.var_with_noise ? c->noise : 0.0, c->opts.var_clamp, c->opts.var_min, var);
-  B7_HIP(c, hipGetLastError());
-  return B7_OK;
+  if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
+  int v = c->post_variant;
+  if (v == 2 && (c->Npad % 256)) v = 7;
+  switch (v) {
+    case 0: return launch_post_variant<128, 128, 2, 2, 1, 2, false>(c, ks, row0, rows, Mtotal, var);  // 1 wave/SIMD
+    case 2: return launch_post_variant<256, 128, 4, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, tall
+    case 3: return launch_post_variant<128, 256, 2, 4, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, wide
+    case 4: return launch_post_variant<128, 128, 2, 2, 2, 1, false>(c, ks, row0, rows, Mtotal, var);  // odd LDS stride
+    case 5: return launch_post_variant<128, 128, 2, 2, 2, 2, true>(c, ks, row0, rows, Mtotal, var);   // zero-strip skip
+    case 6: return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both
+    case 7: return launch_post_variant<128, 256, 2, 4, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, wide
+    default: return launch_post_variant<128, 128, 2, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var); // 2 blocks/CU
+  }
 }

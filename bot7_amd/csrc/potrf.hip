@@ -20,6 +20,9 @@
 #include "b7_internal.h"
 #include "gemm_f64.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 constexpr int NB = B7_PANEL;  // 64
@@ -38,57 +41,169 @@ __global__ void __launch_bounds__(256)
   L[e] = v;
 }
 
-// Factor the diagonal block p in LDS, write L11 (upper zeroed) and inv(L11) (upper zeroed).
+// ---- 64x64 diagonal block: factor and invert, blocked by 16 -----------------------------------------------------
+// The serial part of the whole Cholesky.  Per 16-wide sub-block kb: wave 0 factors the 16x16 diagonal sub-block
+// with one matrix row per lane (16 registers), pivots and multipliers broadcast with DPP row_share (no LDS, no
+// barriers), and inverts it the same way; then the sub-panel below (x inv(L_kk)') and the trailing update inside
+// the 64x64 block run as 16x16x16 MFMA products spread over the four waves.  The 64x64 inverse is assembled from
+// the four 16x16 inverses by two doubling levels (X = -inv(C) * (B * inv(A))), again on MFMA; the f64 accumulator
+// layout (row = (l>>4)+4r) is exactly the B-operand layout of k-step r, so T = B*inv(A) feeds the second product
+// straight from registers.
+constexpr int DLD = NB + 2;  // LDS row stride: = 2 (mod 4) doubles -> conflict-free ds_read_b64 fragments
+constexpr int TLD = 34;
+
+template <int J>
+__device__ __forceinline__ double row_share(double v) {  // value of lane J of this lane's 16-lane row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 __global__ void __launch_bounds__(256)
     potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info) {
-  __shared__ double a[NB][NB + 1];
-  __shared__ double x[NB][NB + 1];
-  const int tid = threadIdx.x;
+  extern __shared__ __align__(16) double dsm[];
+  double *A = dsm;                  // [64][DLD] working copy of the block, becomes L11
+  double *X = dsm + NB * DLD;       // [64][DLD] inverse of L11 (zero above the diagonal)
+  double *T = X + NB * DLD;         // [32][TLD] scratch of the last doubling level
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
   double *blk = L + ((int64_t)p * NB) * ld + (int64_t)p * NB;
   for (int e = tid; e < NB * NB; e += 256) {
     int i = e >> 6, j = e & 63;
-    a[i][j] = blk[(int64_t)i * ld + j];
-    x[i][j] = 0.0;
+    A[i * DLD + j] = blk[(int64_t)i * ld + j];
+    X[i * DLD + j] = 0.0;
   }
   __syncthreads();
-  for (int j = 0; j < NB; ++j) {
-    if (tid == 0) {
-      double piv = a[j][j];
-      if (!(piv > 0.0)) {  // also catches NaN, as dpotrf's "ajj <= 0 or isnan" test
-        if (info[0] == 0) info[0] = p * NB + j + 1;
-        piv = 1.0;  // keep the arithmetic finite; the host discards this attempt
+
+  for (int kb = 0; kb < 4; ++kb) {
+    const int o = kb * 16;
+    if (wave == 0) {
+      // every 16-lane row of the wave holds the same 16x16 sub-block (lane lr = matrix row lr)
+      double a[16], r[16], x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = A[(o + lr) * DLD + o + k];
+      static_for<16>([&](auto Jc) {
+        constexpr int j = Jc;
+        double pj = row_share<j>(a[j]);
+        if (!(pj > 0.0)) {  // also catches NaN, like dpotrf's test; uniform over the wave
+          if (lane == 0 && info[0] == 0) info[0] = p * NB + o + j + 1;
+          pj = 1.0;  // keep the arithmetic finite; the host discards this attempt
+        }
+        const double dj = sqrt(pj);
+        r[j] = 1.0 / dj;
+        a[j] = (lr == j) ? dj : a[j] * r[j];
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k > j) {
+            const double lk = row_share<k>(a[j]);  // L[k][j]
+            a[k] -= a[j] * lk;                     // meaningful for rows >= k
+          }
+        });
+      });
+      // inverse: lane lr computes column lr of inv(L_kk); x[i] = X[i][lr]
+      static_for<16>([&](auto Ic) {
+        constexpr int i = Ic;
+        double sacc = 0.0;
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k < i) sacc += row_share<i>(a[k]) * x[k];  // L[i][k] * X[k][c]
+        });
+        x[i] = (i == lr) ? r[i] : ((i > lr) ? -(r[i] * sacc) : 0.0);
+      });
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
+          X[(o + k) * DLD + o + lr] = x[k];
+        }
       }
-      a[j][j] = sqrt(piv);
     }
     __syncthreads();
-    const double djj = a[j][j];
-    if (tid > j && tid < NB) a[tid][j] = a[tid][j] / djj;
+    // sub-panel: L_ik = A_ik * inv(L_kk)'  for block rows ib > kb, one 16x16 block per wave
+    {
+      const int ib = kb + 1 + wave;
+      if (ib < 4) {
+        d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          c = mfma_f64(A[(ib * 16 + lr) * DLD + o + 4 * s4 + lq], X[(o + lr) * DLD + o + 4 * s4 + lq], c);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(ib * 16 + lq + 4 * rr) * DLD + o + lr] = c[rr];
+      }
+    }
     __syncthreads();
-    // rank-1 update of the remaining lower triangle: (i, k) with j < k <= i
-    for (int e = tid; e < NB * NB; e += 256) {
-      int i = e >> 6, k = e & 63;
-      if (k > j && i >= k) a[i][k] -= a[i][j] * a[k][j];
+    // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4
+    {
+      int pidx = 0;
+      for (int i = kb + 1; i < 4; ++i)
+        for (int j = kb + 1; j <= i; ++j, ++pidx) {
+          if ((pidx & 3) != wave) continue;
+          d4_t c;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) c[rr] = A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            c = mfma_f64(-A[(i * 16 + lr) * DLD + o + 4 * s4 + lq], A[(j * 16 + lr) * DLD + o + 4 * s4 + lq], c);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr] = c[rr];
+        }
     }
     __syncthreads();
   }
-  // inverse by forward substitution, one column per thread
-  if (tid < NB) {
-    const int cidx = tid;
-    x[cidx][cidx] = 1.0 / a[cidx][cidx];
-    for (int i = cidx + 1; i < NB; ++i) {
-      double s = 0.0;
-      for (int k = cidx; k < i; ++k) s += a[i][k] * x[k][cidx];
-      x[i][cidx] = -s / a[i][i];
-    }
+
+  // doubling level 16 -> 32: pairs (0,1) and (2,3), one per wave; X_10 = -inv(L_11) * (L_10 * inv(L_00))
+  if (wave < 2) {
+    const int a0 = wave * 32, c0 = a0 + 16;
+    d4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      t = mfma_f64(A[(c0 + lr) * DLD + a0 + 4 * s4 + lq], X[(a0 + 4 * s4 + lq) * DLD + a0 + lr], t);
+    d4_t xx = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) xx = mfma_f64(-X[(c0 + lr) * DLD + c0 + 4 * s4 + lq], t[s4], xx);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) X[(c0 + lq + 4 * rr) * DLD + a0 + lr] = xx[rr];
+  }
+  __syncthreads();
+  // doubling level 32 -> 64: T = L[32:64, 0:32] * X[0:32, 0:32]; X[32:64, 0:32] = -X[32:64, 32:64] * T
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    d4_t t = {0.0, 0.0, 0.0, 0.0};
+    for (int kt = tj; kt < 2; ++kt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        t = mfma_f64(A[(32 + ti * 16 + lr) * DLD + kt * 16 + 4 * s4 + lq],
+                     X[(kt * 16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t[rr];
+    __syncthreads();
+    d4_t xx = {0.0, 0.0, 0.0, 0.0};
+    for (int kt = 0; kt <= ti; ++kt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        xx = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 32 + kt * 16 + 4 * s4 + lq],
+                      T[(kt * 16 + 4 * s4 + lq) * TLD + tj * 16 + lr], xx);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = xx[rr];
   }
   __syncthreads();
   double *dv = dinv + (int64_t)p * NB * NB;
   for (int e = tid; e < NB * NB; e += 256) {
     int i = e >> 6, j = e & 63;
-    blk[(int64_t)i * ld + j] = (j <= i) ? a[i][j] : 0.0;
-    dv[e] = (j <= i) ? x[i][j] : 0.0;
+    blk[(int64_t)i * ld + j] = (j <= i) ? A[i * DLD + j] : 0.0;
+    dv[e] = X[i * DLD + j];
   }
 }
+constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
 
 // L21 tile <- A21 tile * inv(L11)'   (in place; the tile is fully read before it is written).
 __global__ void __launch_bounds__(256)
@@ -220,9 +335,11 @@ int launch_potrf(b7_ctx *c, double extra) {
   hipLaunchKernelGGL(copy_lower_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                      (const double *)c->K.p, L, n, c->N, extra);
   B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   for (int p = 0; p < nb; ++p) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, c->stream, L, n, p, (double *)c->dinv.p,
-                       (int *)c->info.p);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                       (double *)c->dinv.p, (int *)c->info.p);
     const int T = nb - p - 1;
     if (T > 0) {
       hipLaunchKernelGGL(potrf_trsm_kernel, dim3(T), dim3(256), 0, c->stream, L, n, p, (const double *)c->dinv.p);

@@ -114,6 +114,11 @@ int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
 int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp,
               double *nll_out, double *jitter_used, int *info);
 
+/* utils.math.chol(src, 'L') (utils/math.lua:159-218) on a caller-provided symmetric n x n matrix: lower factor
+ * with the same jitter schedule as b7_gp_fit.  res_host n x n (upper triangle zero).  Replaces the current fit
+ * on this context.  jitter_used / info as in b7_gp_fit (nullable). */
+int b7_chol(b7_ctx *ctx, const double *src_host, int n, double *res_host, double *jitter_used, int *info);
+
 /* Second half of model:predict over the resident candidate grid: mean = m + K(X*,X) alpha (M x ycols),
  * var = amp - colsumsq(L^-1 K(X*,X)') (M).  Results stay on the device for the score calls; host copies
  * are optional. */

@@ -28,6 +28,7 @@ typedef struct { double jitter_eps; double jitter_growth; int var_with_noise; in
 int  b7_gp_default_opts(b7_gp_opts *out);
 int  b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
 int  b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info);
+int  b7_chol(b7_ctx *ctx, const double *src_host, int n, double *res_host, double *jitter_used, int *info);
 int  b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 int  b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_host, double *var_host);
 int  b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
