@@ -295,7 +295,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   c->N = N;
   c->Npad = (int)round_up(N, B7_NPAD);
   c->dfit = d;
-  c->dpad = (int)round_up(d, 4);
+  c->dpad = b7_dpad_class(d);
   c->ycols = ycols;
   c->amp = hyp->amp;
   c->noise = hyp->noise;

@@ -13,7 +13,10 @@
 constexpr int B7_NPAD = 128;  // observations padded to a multiple of this (post kernel's n-tile)
 constexpr int B7_PANEL = 64;  // Cholesky panel width / small-GEMM tile
 constexpr int B7_MROWS = 256; // chunk rows are multiples of this (largest candidates-per-block of any post variant)
-constexpr int B7_MAX_D = 128; // LDS budget of the covariance kernel: 128 rows x (dpad+2) doubles <= 160 KiB
+constexpr int B7_MAX_D = 96;  // LDS budget of the covariance kernel: (64 + 2*64) rows x (dpad+1) doubles <= 160 KiB
+
+// Padded input dimension: the covariance kernel is instantiated per class so its MFMA chain unrolls.
+static inline int b7_dpad_class(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 96; }
 
 struct DevBuf {
   void *p = nullptr;
@@ -45,7 +48,7 @@ struct b7_ctx {
   DevBuf xobs;   // N x d raw observations
   DevBuf w;      // dpad inverse squared lengthscales (0 in the padding)
   DevBuf zsc;    // Npad x dpad: observations scaled by w (0 in the padding)
-  DevBuf zss;    // Npad: sum z^2 w  (+inf in the padding -> covariance 0)
+  DevBuf zss;    // Npad: (sum z^2 w)/2  (+inf in the padding -> covariance 0)
   DevBuf K;      // Npad x Npad: K(X,X)+noise*I as assembled (kept for the jitter retries)
   DevBuf L;      // Npad x Npad: lower Cholesky factor (upper triangle zero)
   DevBuf Linv;   // Npad x Npad: explicit inverse of L (upper triangle zero)

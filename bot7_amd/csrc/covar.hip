@@ -8,19 +8,26 @@
 //
 // Layout: the inner product X (Z' .* w) runs on v_mfma_f64_16x16x4_f64 with the query rows as the A operand
 // and the pre-scaled observations (z .* w, zero-padded to dpad = 4*ceil(d/4)) as B.  A block owns 64 query
-// rows and walks ALL observations in slabs of 64, so it sees whole rows of K(X*,X): the posterior-mean dot
+// rows and walks observations in slabs of 64 (double-buffered in LDS, next slab prefetched into registers while
+// the current one is consumed, one barrier per slab), so it sees whole rows of K(X*,X): the posterior-mean dot
 // product with alpha is accumulated in registers on the way and needs no second pass over K*.
-// Each wave stores 4 rows x 16 consecutive doubles (four full 128-byte lines) per accumulator register.
-// Padding observations carry zss = +inf, which makes their covariance exactly 0.
+// Epilogue per element: arg = (c - xs/2) - zs/2 (the reference's ((-2c + xs) + zs) scaled by the exact factor
+// -1/2, same rounding points), clamp to <= 0 (NaN passes, as TH's clamp), amp * exp(arg).  Lane pairs swap one
+// value (DPP quad_perm) so every lane stores 16 bytes: 2 stores per 16x16 tile instead of 4.
+// Padding observations carry zs/2 = +inf, which makes their covariance exactly 0.
+//
+// Priced by ablation on MI355X (tools/ksx_ab.py, 262144 x 2048, d = 32) before this structure: full 2.09 ms,
+// without stores 1.49, without exp 2.02, without MFMA 1.74 -> the old kernel was bound by its own staging
+// (integer division per element, two barriers per slab, no prefetch), not by arithmetic or HBM.
 #include "b7_internal.h"
 #include "gemm_f64.h"
 
 namespace {
 
-// ---- observation pre-scaling: zsc = z .* w (padded), zss = sum z^2 w --------------------------------------
+// ---- observation pre-scaling: zsc = z .* w (padded), zsh = (sum z^2 w)/2 ---------------------------------------
 __global__ void __launch_bounds__(256) prep_obs_kernel(const double *__restrict__ xobs, const double *__restrict__ ls,
                                                        double *__restrict__ w, double *__restrict__ zsc,
-                                                       double *__restrict__ zss, int N, int Npad, int d, int dpad) {
+                                                       double *__restrict__ zsh, int N, int Npad, int d, int dpad) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < dpad) w[i] = (i < d) ? 1.0 / ls[i] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
   if (i >= Npad) return;
@@ -31,80 +38,181 @@ __global__ void __launch_bounds__(256) prep_obs_kernel(const double *__restrict_
     zsc[(int64_t)i * dpad + k] = z * wk;
     s += (z * z) * wk;  // Z_ss = (Z.^2) * inv_ls, :79
   }
-  zss[i] = (i < N) ? s : __builtin_inf();
+  zsh[i] = (i < N) ? 0.5 * s : __builtin_inf();
+}
+
+// exp(x) for x <= 0 (or NaN): k = rint(x log2 e), r = x - k ln2 in two pieces, Taylor to r^13 (|r| <= ln2/2:
+// truncation 4e-18), scale by 2^k with v_ldexp (gradual underflow for k < -1022).  No special-case branches.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = (x < -1000.0) ? -1000.0 : x;  // -inf (padding) and anything that underflows anyway; NaN passes
+  const double kf = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                      // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);          // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);         // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);         // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);        // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);          // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);         // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);         // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);         // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);        // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);        // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+
+__device__ __forceinline__ double pair_swap(double v) {  // value held by lane ^ 1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
 }
 
 // ---- K(X*,X) chunk / K(X,X) -----------------------------------------------------------------------------------
 // xq: query rows, row-major with d columns; rows [row0, row0+rows) of a set with Mtotal rows (rows beyond
 // Mtotal-1 are clamped: they produce values nobody reads).  out: rows x Npad (leading dimension Npad).
-// mu (nullable): mean + K* alpha for ycols == 1.
+// mu (nullable): mean + K* alpha for ycols == 1.  blockIdx.y splits the observations into gridDim.y equal
+// ranges of whole slabs (used for K(X,X), where there are few query rows; mu must then be null).
 constexpr int KQ = 64;  // query rows per block (16 per wave)
 constexpr int KO = 64;  // observation slab
 
-// ABLATE (diagnostic builds only, B7_KSX_ABLATE): 0 = product; 1 = no stores; 2 = no exp; 3 = no MFMA.
-template <int ABLATE>
+// DPAD = padded input dimension, one of the classes {4, 8, 16, 32, 64, 96} (b7_dpad_class): compile-time so that
+// the MFMA chain over DPAD/4 k-steps unrolls and the query fragments stay in registers for the whole block.
+// ABLATE (diagnostic, B7_KSX_ABLATE): 0 = product; 1 = no stores; 2 = no exp; 3 = no MFMA.
+template <int DPAD, int ABLATE>
 __global__ void __launch_bounds__(256)
-    ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad,
-               const double *__restrict__ w, const double *__restrict__ zsc, const double *__restrict__ zss,
+    ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad_rt,
+               const double *__restrict__ w, const double *__restrict__ zsc, const double *__restrict__ zsh,
                const double *__restrict__ alpha, double amp, double meanc, int Npad, double *__restrict__ out,
                double *__restrict__ mu) {
   extern __shared__ __align__(16) double sm[];
-  const int stride = dpad + 2;
-  double *sq = sm;                        // KQ x stride
-  double *so = sm + KQ * stride;          // KO x stride
-  double *sxs = so + KO * stride;         // KQ
+  constexpr int dpad = DPAD, NCH = (DPAD + 7) / 8, KSTEPS = DPAD / 4;
+  constexpr int stride = DPAD + 1;  // odd: conflict-free for the fused ds_read2_b64 fragment reads (gemm_f64.h)
+  (void)dpad_rt;
+  double *sq = sm;                          // KQ x stride
+  double *so = sq + KQ * stride;            // 2 x KO x stride
+  double *sh = so + 2 * KO * stride;        // 2 x KO   zs/2 of the slab
+  double *sal = sh + 2 * KO;                // 2 x KO   alpha of the slab
+  double *shq = sal + 2 * KO;               // KQ       xs/2 of the queries
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
   const int64_t qbase = row0 + (int64_t)blockIdx.x * KQ;
+  const int srow = tid >> 2, sq4 = tid & 3;  // staging: 4 threads per row
+  constexpr int half = DPAD >> 1;            // 16-byte chunks per row
 
-  // stage the query tile (zero-padded columns), one row-major pass
-  for (int e = tid; e < KQ * dpad; e += 256) {
-    int r = e / dpad, k = e - r * dpad;
-    int64_t g = qbase + r;
+  // query tile (zero-padded columns)
+  {
+    int64_t g = qbase + srow;
     if (g > Mtotal - 1) g = Mtotal - 1;
-    sq[r * stride + k] = (k < d) ? xq[g * d + k] : 0.0;
+    for (int k = sq4; k < dpad; k += 4) sq[srow * stride + k] = (k < d) ? xq[g * d + k] : 0.0;
   }
-  __syncthreads();
+  const int nslab_total = Npad / KO;
+  const int nslab = nslab_total / gridDim.y;
+  const int slab0 = blockIdx.y * nslab;
+
+  d2_t pre[NCH];
+  double pre_h = 0.0, pre_a = 0.0;
+  auto load_slab = [&](int s) {
+    const double *src = zsc + (int64_t)(s * KO + srow) * dpad;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int kc = i * 4 + sq4;
+      if (kc < half) pre[i] = *reinterpret_cast<const d2_t *>(src + 2 * kc);
+    }
+    if (tid < KO) {
+      pre_h = zsh[s * KO + tid];
+      pre_a = alpha ? alpha[s * KO + tid] : 0.0;
+    }
+  };
+  auto store_slab = [&](int buf) {
+    double *dst = so + buf * KO * stride + srow * stride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int kc = i * 4 + sq4;
+      if (kc < half) {
+        dst[2 * kc] = pre[i][0];
+        dst[2 * kc + 1] = pre[i][1];
+      }
+    }
+    if (tid < KO) {
+      sh[buf * KO + tid] = pre_h;
+      sal[buf * KO + tid] = pre_a;
+    }
+  };
+
+  load_slab(slab0);
+  __syncthreads();  // query tile visible
   if (tid < KQ) {
     double s = 0.0;
     for (int k = 0; k < dpad; ++k) {
       double x = sq[tid * stride + k];
       s += (x * x) * w[k];  // X_ss = (X.^2) * inv_ls, :78
     }
-    sxs[tid] = s;
+    shq[tid] = 0.5 * s;
   }
+  store_slab(0);
+  __syncthreads();
 
-  double macc[4] = {0.0, 0.0, 0.0, 0.0};
-  const int ksteps = dpad / 4;
-  const double *qa = sq + (wave * 16 + (lane & 15)) * stride + (lane >> 4);
+  double hq[4], macc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hq[r] = shq[wave * 16 + lq + 4 * r];
+  double qf[KSTEPS];  // this lane's A fragments: query row (wave*16 + lr), k = 4 k4 + lq
+#pragma unroll
+  for (int k4 = 0; k4 < KSTEPS; ++k4) qf[k4] = sq[(wave * 16 + lr) * stride + lq + 4 * k4];
+  // this lane's 16-byte store slots: even lanes write rows r = 0 and 2, odd lanes rows r = 1 and 3, two columns
+  const bool odd = lane & 1;
+  double *orow = out + ((int64_t)blockIdx.x * KQ + wave * 16 + lq + (odd ? 4 : 0)) * Npad + (lr & ~1);
 
-  for (int o0 = 0; o0 < Npad; o0 += KO) {
-    __syncthreads();  // previous slab fully consumed (and sxs visible on the first pass)
-    for (int e = tid; e < KO * dpad; e += 256) {
-      int r = e / dpad, k = e - r * dpad;
-      so[r * stride + k] = zsc[(int64_t)(o0 + r) * dpad + k];
-    }
-    __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < nslab; ++s) {
+    const bool more = (s + 1) < nslab;
+    if (more) load_slab(slab0 + s + 1);
+    const double *sob = so + cur * KO * stride;
+    const int o0 = (slab0 + s) * KO;
 #pragma unroll
     for (int t = 0; t < KO / 16; ++t) {
-      const double *ob = so + (t * 16 + (lane & 15)) * stride + (lane >> 4);
+      const double *ob = sob + (t * 16 + lr) * stride + lq;
       d4_t c = {0.0, 0.0, 0.0, 0.0};
-      if (ABLATE != 3)
-        for (int s = 0; s < ksteps; ++s) c = mfma_f64(qa[4 * s], ob[4 * s], c);
-      else
-        c[0] = c[1] = c[2] = c[3] = qa[0] * ob[0];
-      const int col = o0 + t * 16 + (lane & 15);
-      const double zs = zss[col];
-      const double al = alpha ? alpha[col] : 0.0;
+      if (ABLATE != 3) {
+        double bf[KSTEPS];
+#pragma unroll
+        for (int k4 = 0; k4 < KSTEPS; ++k4) bf[k4] = ob[4 * k4];
+#pragma unroll
+        for (int k4 = 0; k4 < KSTEPS; ++k4) c = mfma_f64(qf[k4], bf[k4], c);
+      } else {
+        c[0] = c[1] = c[2] = c[3] = qf[0] * ob[0];
+      }
+      const double hk = sh[cur * KO + t * 16 + lr];
+      const double al = sal[cur * KO + t * 16 + lr];
+      double kv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qr = wave * 16 + (lane >> 4) + 4 * r;
-        double dist = (c[r] * -2.0 + sxs[qr]) + zs;  // :82 mul(-2):add(X_ss):add(Z_ss')
-        dist = dist < 0.0 ? 0.0 : dist;             // :106 clamp(0, huge)
-        double kv = (ABLATE == 2) ? amp * (-0.5 * dist) : amp * exp(-0.5 * dist);
-        if (ABLATE != 1) out[((int64_t)blockIdx.x * KQ + qr) * Npad + col] = kv;
-        macc[r] += kv * al;
+        double arg = (c[r] - hq[r]) - hk;  // = -1/2 * (((-2 c) + xs) + zs), utils/math.lua:82
+        arg = (arg > 0.0) ? 0.0 : arg;     // :106 clamp(0, huge) on the distance; NaN passes
+        kv[r] = (ABLATE == 2) ? amp * arg : amp * exp_nonpos(arg);
+        macc[r] = __builtin_fma(kv[r], al, macc[r]);
+      }
+      if (ABLATE != 1) {
+        // rows (lq, lq+4, lq+8, lq+12) x column lr  ->  16-byte stores of two adjacent columns
+        const double s01 = pair_swap(odd ? kv[0] : kv[1]);
+        const double s23 = pair_swap(odd ? kv[2] : kv[3]);
+        d2_t v01, v23;
+        v01[0] = odd ? s01 : kv[0];
+        v01[1] = odd ? kv[1] : s01;
+        v23[0] = odd ? s23 : kv[2];
+        v23[1] = odd ? kv[3] : s23;
+        double *p = orow + o0 + t * 16;
+        *reinterpret_cast<d2_t *>(p) = v01;
+        *reinterpret_cast<d2_t *>(p + (int64_t)8 * Npad) = v23;
       }
     }
+    if (more) store_slab(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
 
   if (mu || ABLATE == 1) {
@@ -115,14 +223,14 @@ __global__ void __launch_bounds__(256)
       v += __shfl_xor(v, 2);
       v += __shfl_xor(v, 4);
       v += __shfl_xor(v, 8);
-      const int64_t g = qbase + wave * 16 + (lane >> 4) + 4 * r;
-      if ((lane & 15) == 0 && g < Mtotal && mu) mu[g] = meanc + v;
+      const int64_t g = qbase + wave * 16 + lq + 4 * r;
+      if (lr == 0 && g < Mtotal && mu) mu[g] = meanc + v;
       if (ABLATE == 1 && !mu && v == 1.2345e300) out[0] = v;  // keeps the arithmetic alive without stores
     }
   }
 }
 
-// K(X,X) post-pass: padding rows/columns become identity, `diag_add` (noise + jitter) goes on the diagonal.
+// K(X,X) post-pass: padding rows/columns become identity, `diag_add` (noise) goes on the diagonal.
 __global__ void __launch_bounds__(256)
     kxx_fix_kernel(double *__restrict__ K, int N, int Npad, double diag_add) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,6 +240,40 @@ __global__ void __launch_bounds__(256)
     K[e] = (i == j) ? 1.0 : 0.0;
   else if (i == j)
     K[e] += diag_add;
+}
+
+size_t ksx_lds_bytes(int dpad) {
+  return sizeof(double) * ((size_t)(KQ + 2 * KO) * (dpad + 1) + 4 * KO + KQ);
+}
+
+template <int DPAD>
+int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const double *alpha,
+               double meanc, double *out, double *mu) {
+  const size_t lds = ksx_lds_bytes(DPAD);
+  auto kern = ksx_kernel<DPAD, 0>;
+  if (c->ksx_ablate == 1) kern = ksx_kernel<DPAD, 1>;
+  if (c->ksx_ablate == 2) kern = ksx_kernel<DPAD, 2>;
+  if (c->ksx_ablate == 3) kern = ksx_kernel<DPAD, 3>;
+  // dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup)
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad, (const double *)c->w.p,
+                     (const double *)c->zsc.p, (const double *)c->zss.p, alpha, c->amp, meanc, c->Npad, out, mu);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int ksx_dispatch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const double *alpha,
+                 double meanc, double *out, double *mu) {
+  switch (c->dpad) {
+    case 4: return ksx_launch<4>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    case 8: return ksx_launch<8>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    case 16: return ksx_launch<16>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    case 32: return ksx_launch<32>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    case 64: return ksx_launch<64>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    case 96: return ksx_launch<96>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    default: return b7_fail(c, B7_ERR_UNSUPPORTED, "covariance kernel: dpad %d is not a built class", c->dpad);
+  }
 }
 
 }  // namespace
@@ -144,50 +286,23 @@ int launch_prep_obs(b7_ctx *c, const double *xobs, const double *ls_dev, int N, 
   return B7_OK;
 }
 
-static size_t ksx_lds_bytes(int dpad) { return sizeof(double) * ((size_t)(KQ + KO) * (dpad + 2) + KQ); }
-
-// Dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup).
-static int ksx_allow_lds(b7_ctx *c, size_t lds) {
-  if (lds > 160 * 1024) return b7_fail(c, B7_ERR_UNSUPPORTED, "covariance kernel: d too large for LDS");
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ksx_kernel<3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  return B7_OK;
-}
-
 int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
                double *mu, int ycols) {
   PhaseScope ps(c, "ksx");
   if (rows % KQ) return b7_fail(c, B7_ERR_INVALID, "ksx: rows %lld not a multiple of %d", (long long)rows, KQ);
   if (ycols != 1 && mu) return b7_fail(c, B7_ERR_UNSUPPORTED, "ksx: fused mean supports ycols == 1");
-  size_t lds = ksx_lds_bytes(c->dpad);
-  B7_TRY(ksx_allow_lds(c, lds));
-  auto kern = ksx_kernel<0>;
-  if (c->ksx_ablate == 1) kern = ksx_kernel<1>;
-  if (c->ksx_ablate == 2) kern = ksx_kernel<2>;
-  if (c->ksx_ablate == 3) kern = ksx_kernel<3>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / KQ)), dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad,
-                     (const double *)c->w.p, (const double *)c->zsc.p, (const double *)c->zss.p,
-                     mu ? (const double *)c->alpha.p : nullptr, c->amp, c->mean, c->Npad, ks, mu);
-  B7_HIP(c, hipGetLastError());
-  return B7_OK;
+  return ksx_dispatch(c, dim3((unsigned)(rows / KQ), 1), xq, row0, Mtotal, d,
+                      mu ? (const double *)c->alpha.p : nullptr, c->mean, ks, mu);
 }
 
 int launch_kxx(b7_ctx *c, double diag_add) {
   PhaseScope ps(c, "kxx");
   const int Npad = c->Npad;
-  size_t lds = ksx_lds_bytes(c->dpad);
-  B7_TRY(ksx_allow_lds(c, lds));
-  hipLaunchKernelGGL(ksx_kernel<0>, dim3(Npad / KQ), dim3(256), lds, c->stream, (const double *)c->xobs.p, (int64_t)0,
-                     (int64_t)c->N, c->dfit, c->dpad, (const double *)c->w.p, (const double *)c->zsc.p,
-                     (const double *)c->zss.p, (const double *)nullptr, c->amp, 0.0, Npad, (double *)c->K.p,
-                     (double *)nullptr);
-  B7_HIP(c, hipGetLastError());
+  // few query rows: split the observations over blockIdx.y so that the grid covers the chip
+  int ny = 1;
+  while (ny < 16 && (Npad / KO) % (ny * 2) == 0 && (Npad / KQ) * ny < 2 * c->cus) ny *= 2;
+  B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, ny), (const double *)c->xobs.p, 0, c->N, c->dfit, nullptr, 0.0,
+                      (double *)c->K.p, nullptr));
   int64_t total = (int64_t)Npad * Npad;
   hipLaunchKernelGGL(kxx_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (double *)c->K.p,
                      c->N, Npad, diag_add);
