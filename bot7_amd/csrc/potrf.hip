@@ -55,8 +55,8 @@ constexpr int TLD = 34;
 template <int J>
 __device__ __forceinline__ double row_share(double v) {  // value of lane J of this lane's 16-lane row
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + J, 0xF, 0xF, true);  // every lane of the row is a valid source
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <class F, int... Is>
@@ -98,9 +98,15 @@ __global__ void __launch_bounds__(256)
           if (lane == 0 && info[0] == 0) info[0] = p * NB + o + j + 1;
           pj = 1.0;  // keep the arithmetic finite; the host discards this attempt
         }
-        const double dj = sqrt(pj);
-        r[j] = 1.0 / dj;
-        a[j] = (lr == j) ? dj : a[j] * r[j];
+        // 1/sqrt(pj): hardware estimate + two Newton steps (quadratic: 2^-26 -> full), then dj = pj * rj.
+        // LAPACK's dpotf2 likewise scales the column by the reciprocal of the pivot's root.
+        double y = __builtin_amdgcn_rsq(pj);
+        const double hp = 0.5 * pj;
+        y = y * __builtin_fma(-hp * y, y, 1.5);
+        y = y * __builtin_fma(-hp * y, y, 1.5);
+        r[j] = y;
+        const double dj = pj * y;
+        a[j] = (lr == j) ? dj : a[j] * y;
         static_for<16>([&](auto Kc) {
           constexpr int k = Kc;
           if constexpr (k > j) {
@@ -305,23 +311,36 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// alpha = Linv' * t : block = 64 columns, 4 waves split the rows, LDS reduce in fixed order.
+// alpha = Linv' * t in two passes with a fixed summation order: partial[ib][col] over 256-row slices, then their
+// sum in ascending ib.  Block = 64 columns x one 256-row slice (4 waves x 64 rows).
+constexpr int TSL = 256;
 __global__ void __launch_bounds__(256)
-    trmv_lower_t_kernel(const double *__restrict__ Linv, const double *__restrict__ t, double *__restrict__ alpha,
-                        int n, int nreal, int ycols) {
+    trmv_lower_t_part_kernel(const double *__restrict__ Linv, const double *__restrict__ t,
+                             double *__restrict__ part, int n, int ycols) {
   __shared__ double red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * TSL + wave * 64;
   for (int cidx = 0; cidx < ycols; ++cidx) {
     double s = 0.0;
-    for (int i = blockIdx.x * 64 + wave; i < n; i += 4)
-      if (i >= col) s += Linv[(int64_t)i * n + col] * t[(int64_t)i * ycols + cidx];
+    if (r0 < n && r0 + 63 >= blockIdx.x * 64)  // Linv[i][col] = 0 for i < col: slices above the diagonal are zero
+      for (int i = r0; i < r0 + 64; ++i) s += Linv[(int64_t)i * n + col] * t[(int64_t)i * ycols + cidx];
     red[wave][threadIdx.x & 63] = s;
     __syncthreads();
-    if (wave == 0) {
-      double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-      alpha[(int64_t)col * ycols + cidx] = (col < nreal) ? v : 0.0;
-    }
+    if (wave == 0)
+      part[((int64_t)blockIdx.y * ycols + cidx) * n + col] =
+          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256)
+    trmv_lower_t_sum_kernel(const double *__restrict__ part, double *__restrict__ alpha, int n, int nreal, int ycols,
+                            int nslices) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= n) return;
+  for (int cidx = 0; cidx < ycols; ++cidx) {
+    double s = 0.0;
+    for (int ib = col / TSL; ib < nslices; ++ib) s += part[((int64_t)ib * ycols + cidx) * n + col];
+    alpha[(int64_t)col * ycols + cidx] = (col < nreal) ? s : 0.0;
   }
 }
 
@@ -375,8 +394,12 @@ int launch_alpha(b7_ctx *c) {
   double *t = (double *)c->W.p;  // W is free after trtri: reuse its first n*ycols entries
   hipLaunchKernelGGL(trmv_lower_kernel, dim3(n / 4), dim3(256), 0, c->stream, (const double *)c->Linv.p,
                      (const double *)c->resid.p, t, n, c->ycols);
-  hipLaunchKernelGGL(trmv_lower_t_kernel, dim3(n / 64), dim3(256), 0, c->stream, (const double *)c->Linv.p,
-                     (const double *)t, (double *)c->alpha.p, n, c->N, c->ycols);
+  const int nslices = (n + TSL - 1) / TSL;
+  double *part = t + (size_t)n * c->ycols;  // W has n*n doubles: room for nslices * ycols * n partials
+  hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices), dim3(256), 0, c->stream,
+                     (const double *)c->Linv.p, (const double *)t, part, n, c->ycols);
+  hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double *)part,
+                     (double *)c->alpha.p, n, c->N, c->ycols, nslices);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
