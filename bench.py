@@ -79,6 +79,20 @@ def cpu_baseline(d, N, objective, score, sample, X_obs, Y, hyp):
             "gp_fit_ms": t_fit * 1e3, "argmax1": int(idx)}
 
 
+def pmc_traffic(rows_per_launch, N):
+    """HBM bytes per post_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, + WRITE_SIZE), when they were taken at this launch shape; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")
+    try:
+        with open(path) as f:
+            p = json.load(f)
+        if int(p["rows_per_launch"]) == int(rows_per_launch) and int(p["n_obs"]) == int(N):
+            return float(p["kernels"]["post_kernel"]["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +106,8 @@ def main():
     import torch
     import torch.distributed as td
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    grouped = "RANK" in os.environ  # launched by torch.distributed.run: join the group even when it has one rank
+    if grouped:
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import bot7_amd
@@ -127,7 +142,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             td.barrier()
             torch.cuda.synchronize()
 
@@ -142,7 +157,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -185,7 +200,11 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "post_kernel (posterior variance: L^-1 K*' with fused column sumsq)",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS if achieved == achieved else None,
-                     "traffic": None,
+                     "traffic": pmc_traffic(rows_per_launch, N),
+                     "traffic_source": "profiles/r01d_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                       "passes of this bench at the same launch shape; K* is re-read ~8.5x by design, "
+                                       "algorithmic bytes per launch = rows*N*8)",
+                     "algorithmic_bytes_per_launch": rows_per_launch * N * 8.0,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": post_avg_s * 1e3,
                      "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s (measured 74.5-77.3, profiles/r01_mfma_f64_probe.txt)"},
         "gp_fit_ms": fit_ms,
@@ -200,7 +219,7 @@ def main():
     if rank == 0:
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if grouped:
         td.barrier()
         td.destroy_process_group()
 

@@ -93,7 +93,7 @@ int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t
   PhaseScope ps(c, "post");
   if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
   int v = c->post_variant;
-  if (v == 2 && (c->Npad % 256)) v = 7;
+  if ((v == 2 || v == 8) && (c->Npad % 256)) v = 7;
   switch (v) {
     case 0: return launch_post_variant<128, 128, 2, 2, 1, 2, false>(c, ks, row0, rows, Mtotal, var);  // 1 wave/SIMD
     case 2: return launch_post_variant<256, 128, 4, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, tall
@@ -102,6 +102,7 @@ int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t
     case 5: return launch_post_variant<128, 128, 2, 2, 2, 2, true>(c, ks, row0, rows, Mtotal, var);   // zero-strip skip
     case 6: return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both
     case 7: return launch_post_variant<128, 256, 2, 4, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, wide
+    case 8: return launch_post_variant<256, 128, 4, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, tall
     default: return launch_post_variant<128, 128, 2, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var); // 2 blocks/CU
   }
 }

@@ -47,7 +47,7 @@ def exchange_best(local_val, local_idx1, lo, device=None, group=None):
     (exact below 2^53)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         if local_idx1 <= 0:
             raise ValueError("every shard is empty")
         return local_val, int(lo + local_idx1)
