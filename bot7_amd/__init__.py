@@ -11,7 +11,7 @@ There is no CPU fallback: importing the package is cheap, but the first call tha
 the library and raises ``Bot7HipError`` if it, or a gfx950 GPU, is missing.
 """
 from ._lib import Bot7HipError, Context, default_context, lib_path  # noqa: F401
-from . import grids, models, scores, bots, utils, benchmarks  # noqa: F401
+from . import grids, models, scores, bots, utils, benchmarks, samplers  # noqa: F401
 
 __all__ = ["Bot7HipError", "Context", "default_context", "lib_path", "grids", "models", "scores", "bots", "utils",
-           "benchmarks"]
+           "benchmarks", "samplers"]

@@ -13,7 +13,13 @@ Everything numerical happens in libbot7hip.so (b7_gp_fit / b7_gp_predict); nothi
 
 Hyper-parameter vector layout (ours; the reference's parse_hypers layout is unknowable from its tree):
     [ lenscale_sq_1 .. lenscale_sq_d, amp, noise, mean ]
-"""
+
+Hyper sampling (config.sampler = 'slice', bots/bayesopt.lua:44): bot7.samplers.slice walks the log posterior
+    log p(theta | X, Y) = -NLL(theta) + log prior(theta),   theta = [log lenscale_sq, log amp, log noise, mean]
+with a flat prior inside explicit bounds (config.bounds; the gp package's priors are unknown).  Every evaluation
+is one device fit (K + Cholesky + log-det + quadratic form, the `GP-fit ms` unit of work).  With
+``config.nBurnin = 0`` and ``config.sample = False`` (default) sample_hypers returns the point estimate, which
+is what the fixed-hyper parity tests and the benchmark use."""
 import numpy as np
 
 from .abstract import abstract
@@ -55,12 +61,61 @@ class gp_regressor(abstract):
         self.hyp = self.parse_hypers(np.concatenate([np.full(d, d / 8.0), [amp, noise, float(np.mean(Y))]]))
         return self.hyp
 
+    # -- theta <-> hyp
+    @staticmethod
+    def _to_theta(h):
+        return np.concatenate([np.log(h["lenscale_sq"]), [np.log(h["amp"]), np.log(max(h["noise"], 1e-300)), h["mean"]]])
+
+    @staticmethod
+    def _from_theta(t):
+        d = t.size - 3
+        return {"lenscale_sq": np.exp(t[:d]), "amp": float(np.exp(t[d])), "noise": float(np.exp(t[d + 1])),
+                "mean": float(t[d + 2])}
+
+    def _bounds(self, X, Y):
+        b = self.config.get("bounds") or {}
+        d = X.shape[1]
+        vy = float(np.var(Y)) or 1.0
+        lo = np.concatenate([np.full(d, np.log(b.get("lenscale_sq_min", 1e-3 * d))), [np.log(b.get("amp_min", 1e-3 * vy)),
+                             np.log(b.get("noise_min", 1e-8 * vy)), b.get("mean_min", float(Y.min()) - 3 * np.sqrt(vy))]])
+        hi = np.concatenate([np.full(d, np.log(b.get("lenscale_sq_max", 1e3 * d))), [np.log(b.get("amp_max", 1e3 * vy)),
+                             np.log(b.get("noise_max", 1e0 * vy)), b.get("mean_max", float(Y.max()) + 3 * np.sqrt(vy))]])
+        return lo, hi
+
+    def log_posterior(self, theta, X_obs, Y_obs):
+        """-NLL on the device + flat prior inside the bounds (-inf outside)."""
+        theta = np.asarray(theta, dtype=np.float64).ravel()
+        lo, hi = self._bounds(X_obs, Y_obs)
+        if (theta < lo).any() or (theta > hi).any() or not np.isfinite(theta).all():
+            return -np.inf
+        self.nEvals = getattr(self, "nEvals", 0) + 1
+        return -float(self.nll(X_obs, Y_obs, self._from_theta(theta))[0])
+
     def sample_hypers(self, X_obs, Y_obs, _a=None, _b=None, state=None):
-        """Returns the current hyper vector.  The reference draws from the marginal-likelihood posterior with
-        bot7.samplers.slice (host control flow; SURVEY 8f-1 'next' row); every density evaluation that sampler
-        asks for is one b7_gp_fit(..., nll_out) -- see ``nll``."""
+        """model:sample_hypers(X, Y[, nil, nil, true]) (bots/bayesopt.lua:68,74) -> flat hyper vector.
+
+        config.sample = True: one slice-sampling update of the chain kept in ``self.theta`` per call with
+        ``state`` set (the driver's per-sample call), ``config.nBurnin`` updates on a call without it (the
+        driver's first call, :68).  config.sample = False (default): the current point estimate."""
+        X = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
+        Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
         if self.hyp is None:
-            self.init(X_obs, Y_obs)
+            self.init(X, Y)
+        if self.config.get("sample"):
+            from ..samplers import registry as Samplers
+            if getattr(self, "_sampler", None) is None:
+                self._sampler = Samplers[self.config.get("sampler", "slice")]()
+                self._sopt = self._sampler.configure(dict(self.config.get("sampler_opt") or {},
+                                                          seed=self.config.get("seed", 0)))
+                self._sopt.setdefault("width", 0.5)
+            if self.config.get("noiseless") and self.hyp["noise"] <= 0.0:
+                self.hyp["noise"] = np.exp(self._bounds(X, Y)[0][-2])
+            theta = self._to_theta(self.hyp)
+            n_updates = 1 if state else int(self.config.get("nBurnin", 0))
+            f = lambda t, _args: self.log_posterior(t, X, Y)  # noqa: E731
+            for _ in range(n_updates):
+                theta = self._sampler.sample(f, theta.reshape(1, -1), dict(self._sopt, nSamples=1), None)[0]
+            self.hyp = self._from_theta(theta)
         h = self.hyp
         return np.concatenate([h["lenscale_sq"], [h["amp"], h["noise"], h["mean"]]])
 

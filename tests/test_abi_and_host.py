@@ -109,3 +109,37 @@ def test_pick_winner_th_semantics(orc):
     v, i = dist.pick_winner(pairs)
     assert np.isnan(v) and i == 301 == orc.c.argmax_first(s)[0]
     assert dist.pick_winner([(1.0, 0), (0.5, 7)]) == (0.5, 7)  # empty shard ignored
+
+
+def test_slice_sampler_defaults_and_distribution():
+    """samplers/slice.lua: defaults (:32-48) and the update itself on densities with known moments."""
+    from bot7_amd.samplers import slice_sampler
+    S = slice_sampler()
+    opt = S.configure({})
+    assert opt["max_step"] == 1e3 and opt["nSamples"] == 1 and opt["step_out"] is True and opt["logspace"] is True
+    assert S.configure({"step_out": False, "logspace": False})["step_out"] is False
+    # 2-D Gaussian, log-space, random directions: chain of 4000 updates
+    mu, sd = np.array([1.0, -2.0]), np.array([0.5, 2.0])
+    logp = lambda x, _a: float(-0.5 * np.sum(((x.ravel() - mu) / sd) ** 2))  # noqa: E731
+    opt = S.configure({"seed": 3, "width": 1.0})
+    x = np.zeros((1, 2))
+    chain = []
+    for _ in range(4000):
+        x = S.sample(logp, x, opt)
+        chain.append(x[0].copy())
+    chain = np.array(chain[500:])
+    assert np.allclose(chain.mean(0), mu, atol=0.15) and np.allclose(chain.std(0), sd, rtol=0.15)
+    # Gibbs variant, linear space, bounded support: uniform on [0,1]^2
+    p = lambda x, _a: 1.0 if ((x >= 0) & (x <= 1)).all() else 0.0  # noqa: E731
+    opt = S.configure({"seed": 4, "width": 0.3, "gibbs": True, "logspace": False})
+    x = np.full((1, 2), 0.5)
+    chain = []
+    for _ in range(3000):
+        x = S.sample(p, x, opt)
+        chain.append(x[0].copy())
+    chain = np.array(chain)
+    assert chain.min() >= 0 and chain.max() <= 1 and np.allclose(chain.mean(0), 0.5, atol=0.05)
+    # deterministic for a fixed seed; nSamples rows all start from X0
+    a = S(logp, np.zeros((1, 2)), {"seed": 9, "nSamples": 3})
+    b = S(logp, np.zeros((1, 2)), {"seed": 9, "nSamples": 3})
+    assert a.shape == (3, 2) and np.array_equal(a, b)

@@ -406,3 +406,59 @@ def test_full_size_metric_config_properties(ctx, orc):
     # (5)
     widx, wval = orc.c.argmax_first(ei)
     assert idx == widx and val == wval
+
+
+# ---- hyper sampling: slice sampler on the host, every density evaluation a device fit ---------------
+def test_nll_and_slice_sampled_hypers(ctx, orc):
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 48, 512, B.hartmann6)
+    model = bot7_amd.models.gp_regressor({"sample": True, "nBurnin": 3, "seed": 11}, context=ctx)
+    # the density the sampler walks is -NLL of the oracle (flat prior inside the bounds)
+    for scale in (0.5, 1.0, 3.0):
+        h = dict(hyp, lenscale_sq=hyp["lenscale_sq"] * scale)
+        f = orc.gp.fit(X_obs, Y, **h)
+        lp = model.log_posterior(model._to_theta(h), X_obs, Y)
+        assert lp == pytest.approx(-float(f.nll[0]), rel=1e-9, abs=1e-7)
+    lo, hi = model._bounds(X_obs, Y)
+    assert model.log_posterior(lo - 1.0, X_obs, Y) == -np.inf
+    # a deliberately poor start; burn-in then 6 per-sample updates as bots/bayesopt.lua:68,73-75 issues them
+    model.hyp = dict(hyp, lenscale_sq=hyp["lenscale_sq"] * 40.0, noise=hyp["amp"] * 0.5)
+    lp0 = model.log_posterior(model._to_theta(model.hyp), X_obs, Y)
+    model.sample_hypers(X_obs, Y)
+    lps, thetas = [], []
+    for _ in range(6):
+        v = model.sample_hypers(X_obs, Y, None, None, True)
+        h = model.parse_hypers(v)
+        t = model._to_theta(h)
+        assert (t >= lo).all() and (t <= hi).all()
+        thetas.append(t)
+        lps.append(model.log_posterior(t, X_obs, Y))
+    assert max(lps) > lp0, "nine slice updates never left a start chosen to be poor"
+    assert len({tuple(np.round(t, 12)) for t in thetas}) > 1, "chain did not move"
+    assert model.nEvals > 20
+    # same seed, same chain
+    m2 = bot7_amd.models.gp_regressor({"sample": True, "nBurnin": 3, "seed": 11}, context=ctx)
+    m2.hyp = dict(hyp, lenscale_sq=hyp["lenscale_sq"] * 40.0, noise=hyp["amp"] * 0.5)
+    m2.sample_hypers(X_obs, Y)
+    v2 = m2.sample_hypers(X_obs, Y, None, None, True)
+    assert np.allclose(m2._to_theta(m2.parse_hypers(v2)), thetas[0], rtol=1e-9, atol=1e-9)
+
+
+def test_bayesopt_with_sampled_hypers_runs(ctx, orc):
+    """The reference-faithful loop: nSamples hyper draws per nomination, scores marginalised on the device."""
+    import bot7_amd
+
+    class H(object):
+        def __init__(self, name):
+            self.name, self.min, self.max, self.size = name, 0.0, 1.0, 1
+
+    cfg = {"bot": {"verbose": 0, "budget": 8, "nInitial": 3, "nSamples": 3, "seed": 2},
+           "grid": {"type": "sobol", "size": 400, "dims": 2}, "score": {"type": "confidence_bound"},
+           "model": {"type": "gp_regressor", "sample": True, "nBurnin": 2, "seed": 5}}
+    bot = bot7_amd.bots.bayesopt(B.braninhoo, [H("x1"), H("x2")], cfg)
+    bot.model._ctx = ctx
+    bot.candidates = bot7_amd.grids.sobol(bot.config["grid"], context=ctx)()
+    best = bot.run_experiment()
+    assert bot.observed.shape == (8, 2) and bot.candidates.shape == (392, 2)
+    assert np.isfinite(best["y"]).all() and float(best["y"].ravel()[0]) == float(bot.responses.min())
+    assert np.array_equal(ctx.grid_download(), np.asarray(bot.candidates))
