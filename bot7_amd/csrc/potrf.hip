@@ -226,25 +226,39 @@ __global__ void __launch_bounds__(256)
       for (int r = 0; r < 4; ++r) tile[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = acc[i][j][r];
 }
 
-// Trailing update: A22[I][J] -= L21[I] L21[J]'  for lower tiles I >= J.
-__global__ void __launch_bounds__(256) potrf_syrk_kernel(double *__restrict__ L, int ld, int p) {
-  const int I = blockIdx.y, J = blockIdx.x;
-  if (J > I) return;
+// Trailing update: A[I][J] -= L[I][kc0 .. kc0+kb) L[J][kc0 .. kc0+kb)'   for block columns J in [j0, j0+ncols) and
+// I >= J (lower tiles only; 1-D grid over exactly those tiles).  kb = 1 updates with one 64-wide panel, kb = 2
+// with two at once (K = 128): the big update is issued once per PAIR of panels, which doubles its work per launch
+// at the same tile count.  The C tile is fetched before the product so its latency hides under the MFMAs.
+__global__ void __launch_bounds__(256, 2)
+    potrf_syrk_kernel(double *__restrict__ L, int ld, int kc0, int kb, int j0, int ncols, int nbt) {
+  int J = j0, rem = blockIdx.x;
+  for (int c = 0; c < ncols; ++c, ++J) {
+    const int h = nbt - J;
+    if (rem < h) break;
+    rem -= h;
+  }
+  const int I = J + rem;
   __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
-  const double *a = L + ((int64_t)(p + 1 + I) * NB) * ld + (int64_t)p * NB;
-  const double *b = L + ((int64_t)(p + 1 + J) * NB) * ld + (int64_t)p * NB;
-  double *cblk = L + ((int64_t)(p + 1 + I) * NB) * ld + (int64_t)(p + 1 + J) * NB;
-  d4_t acc[2][2] = {};
-  G64NT::run(a, ld, b, ld, 0, NB, acc, sm);
+  const double *a = L + ((int64_t)I * NB) * ld + (int64_t)kc0 * NB;
+  const double *b = L + ((int64_t)J * NB) * ld + (int64_t)kc0 * NB;
+  double *cblk = L + ((int64_t)I * NB) * ld + (int64_t)J * NB;
+  d4_t cin[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double *dst = cblk + (int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j);
-        *dst -= acc[i][j][r];
-      }
+      for (int r = 0; r < 4; ++r) cin[i][j][r] = cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)];
+  d4_t acc[2][2] = {};
+  G64NT::run(a, ld, b, ld, 0, kb * NB, acc, sm);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = cin[i][j][r] - acc[i][j][r];
 }
 
 // Linv <- blockdiag(dinv), zero elsewhere.
@@ -356,13 +370,32 @@ int launch_potrf(b7_ctx *c, double extra) {
   B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  for (int p = 0; p < nb; ++p) {
+  // panels in pairs (a, b = a + 1): the narrow update of block column b after panel a, then ONE trailing update
+  // with both panels (K = 128) for everything to the right of b.
+  auto diag = [&](int p) {
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
                        (double *)c->dinv.p, (int *)c->info.p);
-    const int T = nb - p - 1;
-    if (T > 0) {
-      hipLaunchKernelGGL(potrf_trsm_kernel, dim3(T), dim3(256), 0, c->stream, L, n, p, (const double *)c->dinv.p);
-      hipLaunchKernelGGL(potrf_syrk_kernel, dim3(T, T), dim3(256), 0, c->stream, L, n, p);
+  };
+  auto trsm = [&](int p) {
+    if (nb - p - 1 > 0)
+      hipLaunchKernelGGL(potrf_trsm_kernel, dim3(nb - p - 1), dim3(256), 0, c->stream, L, n, p,
+                         (const double *)c->dinv.p);
+  };
+  auto syrk = [&](int kc0, int kb, int j0, int ncols) {
+    int tiles = 0;
+    for (int J = j0; J < j0 + ncols; ++J) tiles += nb - J;
+    if (tiles > 0)
+      hipLaunchKernelGGL(potrf_syrk_kernel, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb);
+  };
+  for (int a = 0; a < nb; a += 2) {
+    const int b = a + 1;
+    diag(a);
+    trsm(a);
+    if (b < nb) {
+      syrk(a, 1, b, 1);               // block column b only
+      diag(b);
+      trsm(b);
+      syrk(a, 2, b + 1, nb - b - 1);  // everything right of b, both panels at once
     }
   }
   B7_HIP(c, hipGetLastError());
