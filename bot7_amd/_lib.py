@@ -19,7 +19,7 @@ ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
-    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_download",
+    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_download",
     "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
@@ -84,6 +84,7 @@ def load():
         "b7_chol": (i32, [vp, vp, i32, vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_gp_predict": (i32, [vp, vp, vp]),
         "b7_gp_predict_at": (i32, [vp, vp, i64, vp, vp]),
+        "b7_gp_fantasize": (i32, [vp, vp, i32, i32, C.c_uint64, vp, vp, vp]),
         "b7_gp_download": (i32, [vp, vp, vp, vp]),
         "b7_score_reset": (i32, [vp]),
         "b7_score_ei": (i32, [vp, vp, dbl]),
@@ -236,6 +237,7 @@ class Context(object):
         jit, info = C.c_double(), C.c_int()
         self._ck(self._L.b7_gp_fit(self._h, _ptr(X), _ptr(Y), N, d, Y.shape[1], C.byref(hyp), _ptr(nll),
                                    C.byref(jit), C.byref(info)))
+        self.ycols = Y.shape[1]
         return {"nll": nll, "jitter": jit.value, "info": info.value}
 
     def chol(self, src):
@@ -252,7 +254,7 @@ class Context(object):
         if not download:
             self._ck(self._L.b7_gp_predict(self._h, None, None))
             return None, None
-        mean = np.empty((M, 1), dtype=np.float64)
+        mean = np.empty((M, getattr(self, "ycols", 1)), dtype=np.float64)
         var = np.empty(M, dtype=np.float64)
         self._ck(self._L.b7_gp_predict(self._h, _ptr(mean), _ptr(var)))
         return mean, var
@@ -261,10 +263,23 @@ class Context(object):
         X1 = _f64(X1)
         if X1.ndim == 1:
             X1 = X1.reshape(1, -1)
-        mean = np.empty((X1.shape[0], 1), dtype=np.float64)
+        mean = np.empty((X1.shape[0], getattr(self, "ycols", 1)), dtype=np.float64)
         var = np.empty(X1.shape[0], dtype=np.float64)
         self._ck(self._L.b7_gp_predict_at(self._h, _ptr(X1), X1.shape[0], _ptr(mean), _ptr(var)))
         return mean, var
+
+    def gp_fantasize(self, X_pend, nFantasies, seed=0, want_moments=False):
+        """nFantasies joint posterior draws at the pending points: P x nFantasies (+ mu_P, Sigma_P)."""
+        Xp = _f64(X_pend)
+        if Xp.ndim == 1:
+            Xp = Xp.reshape(1, -1)
+        P = Xp.shape[0]
+        out = np.empty((P, int(nFantasies)), dtype=np.float64)
+        mu = np.empty(P, dtype=np.float64) if want_moments else None
+        cov = np.empty((P, P), dtype=np.float64) if want_moments else None
+        self._ck(self._L.b7_gp_fantasize(self._h, _ptr(Xp), P, int(nFantasies), int(seed) & (2 ** 64 - 1), _ptr(out),
+                                         _ptr(mu), _ptr(cov)))
+        return (out, mu, cov) if want_moments else out
 
     def gp_download(self, N, ycols=1):
         Lh = np.empty((N, N), dtype=np.float64)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libbot7hip.so")
-SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "posterior.hip", "score.hip"]
+SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "posterior.hip", "score.hip", "extras.hip"]
 HEADERS = [os.path.join(CSRC, "b7_internal.h"), os.path.join(CSRC, "gemm_f64.h"),
            os.path.join(ROOT, "include", "bot7hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

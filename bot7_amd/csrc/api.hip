@@ -122,7 +122,7 @@ void b7_destroy(b7_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar};
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant};
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
     for (int i = 0; i < B7_MAX_TIMERS; ++i) {
@@ -284,7 +284,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   if (!X || !Y || !hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit: NULL argument");
   if (N < 1 || d < 1 || ycols < 1) return b7_fail(c, B7_ERR_INVALID, "gp_fit: N %d d %d ycols %d", N, d, ycols);
   if (d > B7_MAX_D) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: d %d > %d", d, B7_MAX_D);
-  if (ycols != 1) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: ycols %d (fantasies) not built yet", ycols);
+  if (ycols > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: ycols %d > 256", ycols);
   for (int k = 0; k < d; ++k)
     if (!(hyp->lenscale_sq[k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: lenscale_sq[%d] must be > 0", k);
   if (!(hyp->amp > 0.0) || !(hyp->noise >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: amp > 0, noise >= 0");
@@ -297,6 +297,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   c->dfit = d;
   c->dpad = b7_dpad_class(d);
   c->ycols = ycols;
+  c->yld = (ycols == 1) ? 1 : (int)round_up(ycols, 64);
   c->amp = hyp->amp;
   c->noise = hyp->noise;
   c->mean = hyp->mean;
@@ -310,7 +311,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_TRY(b7_ensure(c, c->Linv, nn));
   B7_TRY(b7_ensure(c, c->W, nn));
   B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
-  B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np * ycols));
+  B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np * c->yld));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np * ycols));
   B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
 
@@ -335,7 +336,8 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
     std::vector<double> diag(N), al((size_t)N * ycols);
     B7_HIP(c, hipMemcpy2D(diag.data(), sizeof(double), c->L.p, sizeof(double) * (np + 1), sizeof(double), N,
                           hipMemcpyDeviceToHost));
-    B7_HIP(c, hipMemcpy(al.data(), c->alpha.p, sizeof(double) * (size_t)N * ycols, hipMemcpyDeviceToHost));
+    B7_HIP(c, hipMemcpy2D(al.data(), sizeof(double) * ycols, c->alpha.p, sizeof(double) * c->yld,
+                          sizeof(double) * ycols, N, hipMemcpyDeviceToHost));
     double logdet = 0.0;
     for (int i = 0; i < N; ++i) logdet += log(diag[i]);
     for (int k = 0; k < ycols; ++k) {
@@ -417,6 +419,7 @@ static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, doub
   for (int64_t row0 = 0; row0 < M; row0 += chunk) {
     int64_t rows = Mpad - row0 < chunk ? Mpad - row0 : chunk;
     B7_TRY(launch_ksx(c, xq, row0, rows, M, c->dfit, (double *)c->ks.p, mu, c->ycols));
+    if (c->ycols > 1) B7_TRY(launch_mean_multi(c, (const double *)c->ks.p, row0, rows, M, mu));
     B7_TRY(launch_post(c, (const double *)c->ks.p, row0, rows, M, var));
   }
   return B7_OK;
@@ -494,6 +497,60 @@ int b7_gp_predict_at(b7_ctx *c, const double *X1, int64_t M1, double *mean_host,
   return B7_OK;
 }
 
+int b7_gp_fantasize(b7_ctx *c, const double *X_pend, int P, int n, uint64_t seed, double *Y_out, double *mean_out,
+                    double *cov_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_fantasize: no fit on this context");
+  if (c->ycols != 1) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fantasize: the fit must have one response column");
+  if (!X_pend || P < 1 || n < 1 || !Y_out) return b7_fail(c, B7_ERR_INVALID, "gp_fantasize: bad arguments");
+  if (P > 64) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fantasize: %d pending points > 64", P);
+  B7_HIP(c, hipSetDevice(c->device));
+  const int np = c->Npad, d = c->dfit, dp = c->dpad;
+  // workspace carve-up (doubles): xp 64*d | zsc_p 64*dp | zsh_p 64 | kp 64*np | vt 64*np | g 4096 | kpp 4096 |
+  // S 4096 | dinv 4096 | mu 64 | out P*n | info
+  size_t need = (size_t)64 * d + (size_t)64 * dp + 64 + (size_t)2 * 64 * np + 4 * 4096 + 64 + (size_t)P * n + 16;
+  B7_TRY(b7_ensure(c, c->fant, need * sizeof(double)));
+  double *xp = (double *)c->fant.p, *zscp = xp + (size_t)64 * d, *zshp = zscp + (size_t)64 * dp, *kp = zshp + 64;
+  double *vt = kp + (size_t)64 * np, *g = vt + (size_t)64 * np, *kpp = g + 4096, *S = kpp + 4096, *dv = S + 4096;
+  double *mu = dv + 4096, *out = mu + 64;
+  int *info_dev = (int *)(out + (size_t)P * n + 2);
+  B7_HIP(c, hipMemcpyAsync(xp, X_pend, sizeof(double) * (size_t)P * d, hipMemcpyHostToDevice, c->stream));
+  // K(Xp, X) with the fused mean, then V' = K(Xp,X) L^-T and G = V'V
+  B7_TRY(launch_ksx(c, xp, 0, 64, P, d, kp, mu, 1));
+  B7_TRY(launch_gemm_nt(c, kp, np, (const double *)c->Linv.p, np, vt, np, 64, np, np));
+  B7_TRY(launch_gemm_nt(c, vt, np, vt, np, g, 64, 64, 64, np));
+  // K(Xp, Xp): the pending points as their own observation set, scaled with the fit's lengthscales
+  double *ls_dev = (double *)c->scratch.p;  // still holds the lengthscales of the current fit
+  B7_TRY(launch_prep_obs_aux(c, xp, ls_dev, P, 64, zscp, zshp));
+  const ObsSet op{zscp, zshp, 64};
+  B7_TRY(launch_k_generic(c, xp, 64, P, op, kpp));
+  B7_TRY(launch_fantasy_cov(c, kpp, g, S, P, c->opts.var_with_noise ? c->noise : 0.0));
+  if (cov_out) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    B7_HIP(c, hipMemcpy2D(cov_out, sizeof(double) * P, S, sizeof(double) * 64, sizeof(double) * P, P,
+                          hipMemcpyDeviceToHost));
+  }
+  // factor with the same jitter schedule as utils.math.chol (eps on the ORIGINAL matrix: keep a copy in kpp)
+  B7_HIP(c, hipMemcpyAsync(kpp, S, sizeof(double) * 4096, hipMemcpyDeviceToDevice, c->stream));
+  double eps = c->opts.jitter_eps;
+  int info = 0;
+  for (int attempt = 0;; ++attempt) {
+    B7_TRY(launch_fantasy_factor(c, S, dv, info_dev));
+    B7_HIP(c, hipMemcpyAsync(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (info == 0) break;
+    if (attempt > 4000) return b7_fail(c, B7_ERR_INVALID, "gp_fantasize: posterior covariance cannot be factored");
+    eps = eps * c->opts.jitter_growth;
+    B7_HIP(c, hipMemcpyAsync(S, kpp, sizeof(double) * 4096, hipMemcpyDeviceToDevice, c->stream));
+    B7_TRY(launch_add_diag(c, S, 64, P, eps));
+  }
+  B7_TRY(launch_fantasy_sample(c, S, mu, P, n, seed, out));
+  B7_HIP(c, hipMemcpyAsync(Y_out, out, sizeof(double) * (size_t)P * n, hipMemcpyDeviceToHost, c->stream));
+  if (mean_out) B7_HIP(c, hipMemcpyAsync(mean_out, mu, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
 int b7_gp_download(b7_ctx *c, double *L_host, double *alpha_host, double *Linv_host) {
   if (!c) return B7_ERR_INVALID;
   if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_download: no fit on this context");
@@ -506,7 +563,8 @@ int b7_gp_download(b7_ctx *c, double *L_host, double *alpha_host, double *Linv_h
     B7_HIP(c, hipMemcpy2D(Linv_host, sizeof(double) * N, c->Linv.p, sizeof(double) * np, sizeof(double) * N, N,
                           hipMemcpyDeviceToHost));
   if (alpha_host)
-    B7_HIP(c, hipMemcpy(alpha_host, c->alpha.p, sizeof(double) * N * c->ycols, hipMemcpyDeviceToHost));
+    B7_HIP(c, hipMemcpy2D(alpha_host, sizeof(double) * c->ycols, c->alpha.p, sizeof(double) * c->yld,
+                          sizeof(double) * c->ycols, N, hipMemcpyDeviceToHost));
   return B7_OK;
 }
 

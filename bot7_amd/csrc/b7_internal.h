@@ -43,6 +43,7 @@ struct b7_ctx {
   // ---- fit state
   bool fitted = false;
   int N = 0, Npad = 0, dfit = 0, dpad = 0, ycols = 0;
+  int yld = 1;   // leading dimension of alpha: 1 for one column, else ycols rounded up to 64 (zero padded)
   double amp = 0, noise = 0, mean = 0;
   b7_gp_opts opts;
   DevBuf xobs;   // N x d raw observations
@@ -54,7 +55,7 @@ struct b7_ctx {
   DevBuf Linv;   // Npad x Npad: explicit inverse of L (upper triangle zero)
   DevBuf W;      // Npad x Npad: scratch of the triangular inversion
   DevBuf dinv;   // (Npad/64) x 64 x 64: inverses of L's diagonal blocks
-  DevBuf alpha;  // Npad x ycols (0 in the padding)
+  DevBuf alpha;  // Npad x yld (0 in the padding)
   DevBuf resid;  // Npad x ycols: Y - mean, then L^-1 (Y - mean)
   DevBuf info;   // int[4]: first failing pivot (1-based), 0 if none
   DevBuf ybuf;   // N x ycols raw
@@ -74,6 +75,7 @@ struct b7_ctx {
   DevBuf scratch; // misc (fmin upload, results)
   DevBuf tmpgrid; // predict_at temporary grid
   DevBuf tmpmu, tmpvar;
+  DevBuf fant;   // fantasize workspace (pending-point covariance pieces)
 
   // ---- measurement
   hipEvent_t tev[B7_MAX_TIMERS][2];
@@ -120,6 +122,14 @@ int launch_random_grid(b7_ctx *c, double *out, int64_t size, int dims, uint64_t 
 int launch_remove_row(b7_ctx *c, const double *src, double *dst, int64_t M, int d, int64_t idx0);
 
 // covar.hip
+struct ObsSet {
+  const double *zsc;  // npad x dpad scaled observations
+  const double *zsh;  // npad half norms (+inf in the padding)
+  int npad;
+};
+int launch_prep_obs_aux(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int npad, double *zsc,
+                        double *zsh);
+int launch_k_generic(b7_ctx *c, const double *xq, int64_t rows, int64_t Mtotal, const ObsSet &o, double *out);
 int launch_prep_obs(b7_ctx *c, const double *xobs, const double *lenscale_sq_dev, int N, int d);
 int launch_kxx(b7_ctx *c, double diag_add);
 int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
@@ -132,6 +142,15 @@ int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 
 // posterior.hip
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var);
+
+// extras.hip
+int launch_mean_multi(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *mu);
+int launch_gemm_nt(b7_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int m, int n,
+                   int k);
+int launch_fantasy_cov(b7_ctx *c, const double *kpp, const double *g, double *S, int P, double diag_add);
+int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev);
+int launch_fantasy_sample(b7_ctx *c, const double *Lp, const double *mu, int P, int n, uint64_t seed, double *out);
+int launch_add_diag(b7_ctx *c, double *S, int ld, int n, double v);
 
 // score.hip
 int launch_ei(b7_ctx *c, const double *mu, const double *var, const double *fmin_dev, double tradeoff,

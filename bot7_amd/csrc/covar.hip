@@ -247,8 +247,8 @@ size_t ksx_lds_bytes(int dpad) {
 }
 
 template <int DPAD>
-int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const double *alpha,
-               double meanc, double *out, double *mu) {
+int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const ObsSet &o,
+               const double *alpha, double meanc, double *out, double *mu) {
   const size_t lds = ksx_lds_bytes(DPAD);
   auto kern = ksx_kernel<DPAD, 0>;
   if (c->ksx_ablate == 1) kern = ksx_kernel<DPAD, 1>;
@@ -258,20 +258,20 @@ int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mto
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad, (const double *)c->w.p,
-                     (const double *)c->zsc.p, (const double *)c->zss.p, alpha, c->amp, meanc, c->Npad, out, mu);
+                     o.zsc, o.zsh, alpha, c->amp, meanc, o.npad, out, mu);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
 
-int ksx_dispatch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const double *alpha,
-                 double meanc, double *out, double *mu) {
+int ksx_dispatch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const ObsSet &o,
+                 const double *alpha, double meanc, double *out, double *mu) {
   switch (c->dpad) {
-    case 4: return ksx_launch<4>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
-    case 8: return ksx_launch<8>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
-    case 16: return ksx_launch<16>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
-    case 32: return ksx_launch<32>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
-    case 64: return ksx_launch<64>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
-    case 96: return ksx_launch<96>(c, grid, xq, row0, Mtotal, d, alpha, meanc, out, mu);
+    case 4: return ksx_launch<4>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
+    case 8: return ksx_launch<8>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
+    case 16: return ksx_launch<16>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
+    case 32: return ksx_launch<32>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
+    case 64: return ksx_launch<64>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
+    case 96: return ksx_launch<96>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
     default: return b7_fail(c, B7_ERR_UNSUPPORTED, "covariance kernel: dpad %d is not a built class", c->dpad);
   }
 }
@@ -286,12 +286,30 @@ int launch_prep_obs(b7_ctx *c, const double *xobs, const double *ls_dev, int N, 
   return B7_OK;
 }
 
+// A second observation set (the pending points of fantasize) scaled with the CURRENT lengthscales; w is rewritten
+// with the same values.
+int launch_prep_obs_aux(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int npad, double *zsc,
+                        double *zsh) {
+  int n = npad > c->dpad ? npad : c->dpad;
+  hipLaunchKernelGGL(prep_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, xobs, ls_dev, (double *)c->w.p,
+                     zsc, zsh, N, npad, c->dfit, c->dpad);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+// K(Xq, Xobs-set) for an arbitrary observation set: rows x o.npad, no mean.
+int launch_k_generic(b7_ctx *c, const double *xq, int64_t rows, int64_t Mtotal, const ObsSet &o, double *out) {
+  if (rows % KQ || o.npad % KO) return b7_fail(c, B7_ERR_INVALID, "k_generic: extents not multiples of 64");
+  return ksx_dispatch(c, dim3((unsigned)(rows / KQ), 1), xq, 0, Mtotal, c->dfit, o, nullptr, 0.0, out, nullptr);
+}
+
 int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
                double *mu, int ycols) {
   PhaseScope ps(c, "ksx");
   if (rows % KQ) return b7_fail(c, B7_ERR_INVALID, "ksx: rows %lld not a multiple of %d", (long long)rows, KQ);
-  if (ycols != 1 && mu) return b7_fail(c, B7_ERR_UNSUPPORTED, "ksx: fused mean supports ycols == 1");
-  return ksx_dispatch(c, dim3((unsigned)(rows / KQ), 1), xq, row0, Mtotal, d,
+  if (ycols != 1) mu = nullptr;  // the multi-column mean is a GEMM of its own (launch_mean_multi)
+  const ObsSet o{(const double *)c->zsc.p, (const double *)c->zss.p, c->Npad};
+  return ksx_dispatch(c, dim3((unsigned)(rows / KQ), 1), xq, row0, Mtotal, d, o,
                       mu ? (const double *)c->alpha.p : nullptr, c->mean, ks, mu);
 }
 
@@ -301,7 +319,8 @@ int launch_kxx(b7_ctx *c, double diag_add) {
   // few query rows: split the observations over blockIdx.y so that the grid covers the chip
   int ny = 1;
   while (ny < 16 && (Npad / KO) % (ny * 2) == 0 && (Npad / KQ) * ny < 2 * c->cus) ny *= 2;
-  B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, ny), (const double *)c->xobs.p, 0, c->N, c->dfit, nullptr, 0.0,
+  const ObsSet o{(const double *)c->zsc.p, (const double *)c->zss.p, Npad};
+  B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, ny), (const double *)c->xobs.p, 0, c->N, c->dfit, o, nullptr, 0.0,
                       (double *)c->K.p, nullptr));
   int64_t total = (int64_t)Npad * Npad;
   hipLaunchKernelGGL(kxx_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (double *)c->K.p,

@@ -348,17 +348,28 @@ __global__ void __launch_bounds__(256)
 }
 __global__ void __launch_bounds__(256)
     trmv_lower_t_sum_kernel(const double *__restrict__ part, double *__restrict__ alpha, int n, int nreal, int ycols,
-                            int nslices) {
+                            int yld, int nslices) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= n) return;
   for (int cidx = 0; cidx < ycols; ++cidx) {
     double s = 0.0;
     for (int ib = col / TSL; ib < nslices; ++ib) s += part[((int64_t)ib * ycols + cidx) * n + col];
-    alpha[(int64_t)col * ycols + cidx] = (col < nreal) ? s : 0.0;
+    alpha[(int64_t)col * yld + cidx] = (col < nreal) ? s : 0.0;
   }
+  for (int cidx = ycols; cidx < yld; ++cidx) alpha[(int64_t)col * yld + cidx] = 0.0;
 }
 
 }  // namespace
+
+// The 64x64 factor-and-invert kernel on a stand-alone 64x64 matrix (fantasize's pending-point covariance).
+int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev) {
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  B7_HIP(c, hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, S, NB, 0, dinv_tmp, info_dev);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
 
 int launch_potrf(b7_ctx *c, double extra) {
   PhaseScope ps(c, "potrf");
@@ -432,7 +443,7 @@ int launch_alpha(b7_ctx *c) {
   hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices), dim3(256), 0, c->stream,
                      (const double *)c->Linv.p, (const double *)t, part, n, c->ycols);
   hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double *)part,
-                     (double *)c->alpha.p, n, c->N, c->ycols, nslices);
+                     (double *)c->alpha.p, n, c->N, c->ycols, c->yld, nslices);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

@@ -169,5 +169,9 @@ class gp_regressor(abstract):
         return out
 
     def fantasize(self, nFantasies, X_obs, Y_obs, X_pend, hyp=None):
-        raise NotImplementedError("fantasies for pending candidates: SURVEY 8f-2 'next' row (the reference's "
-                                  "driver never passes X_pend, bots/bayesopt.lua:66,76)")
+        """model:fantasize (scores/expected_improvement.lua:57): nPend x nFantasies joint posterior draws at the
+        pending points (b7_gp_fantasize; counter-based normals, config.seed + a call counter)."""
+        self.fit(X_obs, Y_obs, hyp)
+        self._fcalls = getattr(self, "_fcalls", 0) + 1
+        seed = int(self.config.get("seed", 0)) * 1000003 + self._fcalls
+        return self.ctx.gp_fantasize(X_pend, nFantasies, seed)

@@ -26,8 +26,14 @@ class expected_improvement(abstract):
     def eval(self, model, hyp, X_obs, Y_obs, X_hid, X_pend=None, config=None):
         """EI.eval (:43-67): posterior at X_hid, fmins, EI.compute.  Returns the M scores on the host."""
         config = config or self.config
-        if X_pend is not None and np.size(X_pend) > 0:
-            model.fantasize(config["nFantasies"], X_obs, Y_obs, X_pend, hyp)  # :51-60 -> NotImplementedError
+        X_obs = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
+        Y_obs = np.asarray(Y_obs, dtype=np.float64).reshape(X_obs.shape[0], -1)
+        if X_pend is not None and np.size(X_pend) > 0:  # :51-60
+            X_pend = np.atleast_2d(np.asarray(X_pend, dtype=np.float64))
+            nF = int(config["nFantasies"])
+            Y_pend = model.fantasize(nF, X_obs, Y_obs, X_pend, hyp)            # nPend x nFantasies
+            X_obs = np.concatenate([X_obs, X_pend], axis=0)                     # X_obs:cat(X_pend, 1)
+            Y_obs = np.concatenate([np.tile(Y_obs[:, :1], (1, nF)), Y_pend], axis=0)
         model.predict_device(X_obs, Y_obs, X_hid, hyp)  # :63
         ctx = model.ctx
         ctx.score_reset()

@@ -108,7 +108,8 @@ int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
  * scores/confidence_bound.lua:63): K = amp*exp(-pdist(X,X,lenscale_sq)/2) + noise*I with the distance of
  * utils/math.lua:65-111; L = chol(K) with the jitter schedule of utils/math.lua:159-218 (eps <- eps*growth
  * added to the ORIGINAL diagonal until success, or chol(I) once eps > ||K||_F); alpha = K^-1 (Y - mean).
- * X_obs N x d, Y_obs N x ycols.  Outputs (all nullable): nll_out[ycols] negative log marginal likelihood,
+ * X_obs N x d, Y_obs N x ycols (ycols <= 256: fantasy columns share K, L and differ only in alpha).
+ * Outputs (all nullable): nll_out[ycols] negative log marginal likelihood,
  * jitter_used (0 = none, -1 = fell back to chol(I)), info = 1-based first failing pivot of the FIRST
  * attempt (0 = positive definite). */
 int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp,
@@ -127,6 +128,15 @@ int b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 /* model:predict for arbitrary X1 (M1 x d) that is not the resident grid; does not disturb the grid or the
  * score accumulator. */
 int b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_host, double *var_host);
+
+/* model:fantasize(nFantasies, X_obs, Y_obs, X_pend, hyp) (scores/expected_improvement.lua:57; the class is in the
+ * absent `gp` package): nFantasies joint draws from the posterior of the CURRENT fit at the P pending points,
+ * y = mu_P + chol(Sigma_P) z with Sigma_P = K(Xp,Xp) - K(Xp,X) K^-1 K(X,Xp) (+ noise when var_with_noise) factored
+ * with the utils.math.chol jitter schedule.  torch.randn is replaced by a counter-based generator:
+ * z(k, s) = Box-Muller of splitmix64(seed, 2(k n + s) + 1 | + 2).  Y_out P x nFantasies; mean_out[P] and
+ * cov_out[P x P] (nullable) expose mu_P and Sigma_P.  P <= 64; the fit must have ycols == 1. */
+int b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, uint64_t seed, double *Y_out,
+                    double *mean_out, double *cov_out);
 
 /* Inspection (tests): lower Cholesky factor N x N, alpha N x ycols, explicit inverse factor N x N. */
 int b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);

@@ -31,6 +31,7 @@ int  b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int
 int  b7_chol(b7_ctx *ctx, const double *src_host, int n, double *res_host, double *jitter_used, int *info);
 int  b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 int  b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_host, double *var_host);
+int  b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, uint64_t seed, double *Y_out, double *mean_out, double *cov_out);
 int  b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
 int  b7_score_reset(b7_ctx *ctx);
 int  b7_score_ei(b7_ctx *ctx, const double *fmin, double tradeoff);

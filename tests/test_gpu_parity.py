@@ -462,3 +462,66 @@ def test_bayesopt_with_sampled_hypers_runs(ctx, orc):
     assert bot.observed.shape == (8, 2) and bot.candidates.shape == (392, 2)
     assert np.isfinite(best["y"]).all() and float(best["y"].ravel()[0]) == float(bot.responses.min())
     assert np.array_equal(ctx.grid_download(), np.asarray(bot.candidates))
+
+
+# ---- fantasy columns and pending points ----------------------------------------------------------------
+def test_multi_column_fit_predict_and_ei(ctx, orc):
+    """Y with c columns: K, L shared, alpha N x c, mean M x c, EI row-averaged (scores/expected_improvement.lua:83-85)."""
+    X_obs, Y1, X_hid, hyp = make_problem(ctx, orc, 6, 70, 900, B.hartmann6)
+    rng = np.random.default_rng(3)
+    for c in (2, 7, 100):
+        Y = Y1 + 0.1 * rng.normal(size=(70, c))
+        f = orc.gp.fit(X_obs, Y, **hyp)
+        out = ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+        assert np.allclose(out["nll"], f.nll, rtol=1e-9, atol=1e-7)
+        _, alpha, _ = ctx.gp_download(70, c)
+        assert np.allclose(alpha, f.alpha, rtol=1e-6, atol=1e-6 * np.abs(f.alpha).max())
+        ctx.grid_upload(X_hid)
+        mu, var = ctx.gp_predict()
+        mu_o, var_o = orc.gp.predict(f, X_hid)
+        assert mu.shape == (900, c)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+        fmin = Y.min(axis=0)
+        ctx.score_reset()
+        ctx.score_ei(fmin, 0.0)
+        _, idx, ei = ctx.score_finish(1.0, download=True)
+        want = orc.c.ei(mu_o, var_o, fmin)
+        assert np.allclose(ei, want, rtol=1e-6, atol=1e-9) and idx == orc.c.argmax_first(want)[0]
+    ctx.gp_fit(X_obs, Y1, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])  # back to one column
+
+
+def test_fantasize_moments_and_pending_ei(ctx, orc):
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 60, 700, B.hartmann6)
+    X_pend = X_hid[[5, 300, 650]]                      # three pending points
+    ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+    Yp, mu_p, cov_p = ctx.gp_fantasize(X_pend, 20000, seed=7, want_moments=True)
+    f = orc.gp.fit(X_obs, Y, **hyp)
+    mu_o, _ = orc.gp.predict(f, X_pend)
+    Ks = orc.gp.ardse(X_pend, X_obs, hyp["lenscale_sq"], hyp["amp"])
+    from scipy.linalg import solve_triangular
+    V = solve_triangular(f.L, Ks.T, lower=True)
+    cov_o = orc.gp.ardse(X_pend, None, hyp["lenscale_sq"], hyp["amp"]) - V.T @ V
+    assert np.allclose(mu_p, mu_o[:, 0], rtol=1e-7, atol=1e-9)
+    assert np.allclose(cov_p, cov_o, rtol=1e-6, atol=1e-8 * hyp["amp"])
+    # the draws have those moments (20000 samples: 4-sigma bands) and are reproducible per seed
+    sd = np.sqrt(np.diag(cov_o))
+    assert np.all(np.abs(Yp.mean(axis=1) - mu_p) < 4 * sd / np.sqrt(20000))
+    emp = np.cov(Yp)
+    assert np.allclose(emp, cov_o, atol=0.05 * np.outer(sd, sd).max())
+    assert np.array_equal(ctx.gp_fantasize(X_pend, 50, seed=7), ctx.gp_fantasize(X_pend, 50, seed=7))
+    assert not np.array_equal(ctx.gp_fantasize(X_pend, 50, seed=8), ctx.gp_fantasize(X_pend, 50, seed=7))
+    # EI with pending points, end to end through the score class; the oracle scores the SAME fantasies
+    model = bot7_amd.models.gp_regressor({"seed": 4}, context=ctx)
+    model.hyp = hyp
+    score = bot7_amd.scores.expected_improvement({"nFantasies": 16})
+    got = score(model, hyp, X_obs, Y, X_hid, X_pend)
+    model._fcalls = 0                                  # replay the same fantasy draw
+    Y_pend = model.fantasize(16, X_obs, Y, X_pend, hyp)
+    X2 = np.concatenate([X_obs, X_pend])
+    Y2 = np.concatenate([np.tile(Y, (1, 16)), Y_pend])
+    f2 = orc.gp.fit(X2, Y2, **hyp)
+    mu2, var2 = orc.gp.predict(f2, X_hid)
+    want = orc.c.ei(mu2, var2, Y2.min(axis=0))
+    assert got.shape == (700,) and np.allclose(got, want, rtol=1e-5, atol=1e-9)
+    assert int(np.argmax(got)) == int(np.argmax(want))
