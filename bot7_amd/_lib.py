@@ -20,7 +20,7 @@ SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_download",
-    "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
+    "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
 
@@ -34,6 +34,14 @@ class Bot7HipError(RuntimeError):
 class Hyp(C.Structure):
     _fields_ = [("lenscale_sq", C.POINTER(C.c_double)), ("amp", C.c_double), ("noise", C.c_double),
                 ("mean", C.c_double)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("dims", C.POINTER(C.c_int)), ("W", C.POINTER(C.POINTER(C.c_double))),
+                ("b", C.POINTER(C.POINTER(C.c_double))), ("activation", C.c_int)]
+
+
+ACTIVATIONS = {None: 0, "Identity": 0, "Tanh": 1, "ReLU": 2, "Sigmoid": 3}
 
 
 class GpOpts(C.Structure):
@@ -86,6 +94,10 @@ def load():
         "b7_gp_predict_at": (i32, [vp, vp, i64, vp, vp]),
         "b7_gp_fantasize": (i32, [vp, vp, i32, i32, C.c_uint64, vp, vp, vp]),
         "b7_gp_download": (i32, [vp, vp, vp, vp]),
+        "b7_blr_basis": (i32, [vp, C.POINTER(Mlp), vp, i64, vp]),
+        "b7_blr_features": (i32, [vp, vp, i64, i32]),
+        "b7_blr_fit": (i32, [vp, vp, vp, i32, i32, dbl, dbl, dbl, C.POINTER(dbl)]),
+        "b7_blr_predict": (i32, [vp, vp, vp]),
         "b7_score_reset": (i32, [vp]),
         "b7_score_ei": (i32, [vp, vp, dbl]),
         "b7_score_cb": (i32, [vp, dbl, i32, dbl]),
@@ -287,6 +299,59 @@ class Context(object):
         Li = np.empty((N, N), dtype=np.float64)
         self._ck(self._L.b7_gp_download(self._h, _ptr(Lh), _ptr(al), _ptr(Li)))
         return Lh, al, Li
+
+    # ---- DNGO: basis network + Bayesian linear head
+    @staticmethod
+    def _mlp(weights, biases, activation):
+        Ws = [_f64(w) for w in weights]
+        bs = [_f64(b).ravel() for b in biases]
+        n = len(Ws)
+        dims = (C.c_int * (n + 1))(*([Ws[0].shape[1]] + [w.shape[0] for w in Ws]))
+        Wp = (C.POINTER(C.c_double) * n)(*[w.ctypes.data_as(C.POINTER(C.c_double)) for w in Ws])
+        bp = (C.POINTER(C.c_double) * n)(*[b.ctypes.data_as(C.POINTER(C.c_double)) for b in bs])
+        m = Mlp(n, dims, Wp, bp, ACTIVATIONS[activation])
+        m._keep = (Ws, bs, dims, Wp, bp)
+        return m
+
+    def blr_basis(self, weights, biases, activation="Tanh", X=None, download=False):
+        """Features of X (host rows) or, with X=None, of the resident grid (kept on the device)."""
+        net = self._mlp(weights, biases, activation)
+        z = net._keep[0][-1].shape[0]
+        if X is None:
+            M, _ = self.grid_shape()
+            out = np.empty((M, z), dtype=np.float64) if download else None
+            self._ck(self._L.b7_blr_basis(self._h, C.byref(net), None, 0, _ptr(out)))
+            return out
+        X = _f64(X)
+        if X.ndim == 1:
+            X = X.reshape(1, -1)
+        out = np.empty((X.shape[0], z), dtype=np.float64)
+        self._ck(self._L.b7_blr_basis(self._h, C.byref(net), _ptr(X), X.shape[0], _ptr(out)))
+        return out
+
+    def blr_features(self, Z1):
+        Z1 = _f64(Z1)
+        self._ck(self._L.b7_blr_features(self._h, _ptr(Z1), Z1.shape[0], Z1.shape[1]))
+        self.grid_version += 1
+
+    def blr_fit(self, Z0, Y0, alpha_prec, beta, mean=0.0, want_nll=False):
+        Z0 = _f64(Z0)
+        Y0 = _f64(Y0).ravel()
+        nll = C.c_double()
+        self._ck(self._L.b7_blr_fit(self._h, _ptr(Z0), _ptr(Y0), Z0.shape[0], Z0.shape[1], float(alpha_prec),
+                                    float(beta), float(mean), C.byref(nll) if want_nll else None))
+        self.ycols = 1
+        return nll.value if want_nll else None
+
+    def blr_predict(self, download=True):
+        M, _ = self.grid_shape()
+        if not download:
+            self._ck(self._L.b7_blr_predict(self._h, None, None))
+            return None, None
+        mean = np.empty((M, 1), dtype=np.float64)
+        var = np.empty(M, dtype=np.float64)
+        self._ck(self._L.b7_blr_predict(self._h, _ptr(mean), _ptr(var)))
+        return mean, var
 
     # ---- scores
     def score_reset(self):

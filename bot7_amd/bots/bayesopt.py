@@ -42,6 +42,13 @@ class bayesopt(abstract):
         X_obs, Y_obs = self.observed, self.responses
         X_hid = self.candidates if candidates is None else candidates
         model, ctx = self.model, self.model.ctx
+        if model.class_() == "bot7.models.dngo":                  # :65-66: one score call, no marginalisation loop
+            model.predict_device(X_obs, Y_obs, X_hid, None)
+            ctx.score_reset()
+            self.score.add_to(ctx, Y_obs)
+            val, idx, scores = ctx.score_finish(1.0, download=want_scores)
+            self.last_scores = scores
+            return scores, val, idx
         model.sample_hypers(X_obs, Y_obs)                         # :68 (burn-in call)
         nSamples = self.config["bot"]["nSamples"]
         first = True

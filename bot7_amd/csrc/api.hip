@@ -69,6 +69,7 @@ static double *cur_grid(b7_ctx *c) { return (double *)c->grid[c->grid_cur].p; }
 static void invalidate_predictions(b7_ctx *c) {
   c->predicted = false;
   c->acc_valid = false;
+  c->Mfeat = 0;  // DNGO features belong to the grid they were computed from
 }
 
 extern "C" {
@@ -122,7 +123,7 @@ void b7_destroy(b7_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant};
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf};
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
     for (int i = 0; i < B7_MAX_TIMERS; ++i) {
@@ -291,6 +292,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_HIP(c, hipSetDevice(c->device));
 
   c->fitted = false;
+  c->model_kind = 0;
   c->predicted = false;  // the score accumulator survives: marginalisation adds across fits (bots/bayesopt.lua:73-78)
   c->N = N;
   c->Npad = (int)round_up(N, B7_NPAD);
@@ -565,6 +567,177 @@ int b7_gp_download(b7_ctx *c, double *L_host, double *alpha_host, double *Linv_h
   if (alpha_host)
     B7_HIP(c, hipMemcpy2D(alpha_host, sizeof(double) * c->ycols, c->alpha.p, sizeof(double) * c->yld,
                           sizeof(double) * c->ycols, N, hipMemcpyDeviceToHost));
+  return B7_OK;
+}
+
+// ---- DNGO: basis features + Bayesian linear head --------------------------------------------------------------
+static int upload_net(b7_ctx *c, const b7_mlp *net, int *z_out) {
+  if (!net || !net->dims || !net->W || !net->b || net->n_layers < 1 || net->n_layers > 4)
+    return b7_fail(c, B7_ERR_INVALID, "mlp: 1..4 layers with dims, W and b required");
+  size_t total = 0;
+  for (int l = 0; l < net->n_layers; ++l) total += (size_t)net->dims[l + 1] * net->dims[l] + net->dims[l + 1];
+  std::vector<double> pack(total);
+  size_t off = 0;
+  for (int l = 0; l < net->n_layers; ++l) {
+    const size_t nw = (size_t)net->dims[l + 1] * net->dims[l];
+    memcpy(&pack[off], net->W[l], nw * sizeof(double));
+    off += nw;
+    memcpy(&pack[off], net->b[l], (size_t)net->dims[l + 1] * sizeof(double));
+    off += net->dims[l + 1];
+  }
+  B7_TRY(b7_ensure(c, c->netbuf, total * sizeof(double)));
+  B7_HIP(c, hipMemcpy(c->netbuf.p, pack.data(), total * sizeof(double), hipMemcpyHostToDevice));
+  *z_out = net->dims[net->n_layers];
+  return B7_OK;
+}
+
+static int feat_alloc(b7_ctx *c, int64_t M, int z) {
+  const int zpad = (int)round_up(z, B7_NPAD);
+  const size_t bytes = sizeof(double) * (size_t)round_up(M, B7_MROWS) * zpad;
+  B7_TRY(b7_ensure(c, c->feat, bytes));
+  B7_HIP(c, hipMemsetAsync(c->feat.p, 0, bytes, c->stream));
+  c->Mfeat = M;
+  c->zdim = z;
+  c->predicted = false;
+  return B7_OK;
+}
+
+int b7_blr_basis(b7_ctx *c, const b7_mlp *net, const double *X, int64_t M, double *Z_host) {
+  if (!c) return B7_ERR_INVALID;
+  B7_HIP(c, hipSetDevice(c->device));
+  int z = 0;
+  B7_TRY(upload_net(c, net, &z));
+  if (z > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
+  const int zpad = (int)round_up(z, B7_NPAD);
+  if (!X) {  // resident grid -> resident features
+    if (c->M <= 0 || c->d <= 0) return b7_fail(c, B7_ERR_STATE, "blr_basis: no candidate grid on this context");
+    B7_TRY(feat_alloc(c, c->M, z));
+    B7_TRY(launch_mlp_forward(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p,
+                              net->dims, net->n_layers, net->activation, (double *)c->feat.p, zpad));
+    if (Z_host)
+      B7_HIP(c, hipMemcpy2DAsync(Z_host, sizeof(double) * z, c->feat.p, sizeof(double) * zpad, sizeof(double) * z,
+                                 c->M, hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    return B7_OK;
+  }
+  if (M < 1 || !Z_host) return b7_fail(c, B7_ERR_INVALID, "blr_basis: M >= 1 and Z_host required with X");
+  const int d = net->dims[0];
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)M * d));
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * (size_t)M * z));
+  B7_HIP(c, hipMemcpyAsync(c->tmpgrid.p, X, sizeof(double) * (size_t)M * d, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_mlp_forward(c, (const double *)c->tmpgrid.p, M, d, (const double *)c->netbuf.p, net->dims,
+                            net->n_layers, net->activation, (double *)c->tmpmu.p, z));
+  B7_HIP(c, hipMemcpyAsync(Z_host, c->tmpmu.p, sizeof(double) * (size_t)M * z, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_blr_features(b7_ctx *c, const double *Z1, int64_t M, int z) {
+  if (!c) return B7_ERR_INVALID;
+  if (!Z1 || M < 1 || z < 1 || z > 256) return b7_fail(c, B7_ERR_INVALID, "blr_features: bad arguments");
+  B7_HIP(c, hipSetDevice(c->device));
+  const int zpad = (int)round_up(z, B7_NPAD);
+  B7_TRY(feat_alloc(c, M, z));
+  B7_HIP(c, hipMemcpy2DAsync(c->feat.p, sizeof(double) * zpad, Z1, sizeof(double) * z, sizeof(double) * z, M,
+                             hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->M != M) {  // features stand in for a grid: the score calls size themselves by M
+    c->M = M;
+    c->d = 0;
+    c->acc_valid = false;
+  }
+  return B7_OK;
+}
+
+int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta,
+               double mean, double *nll_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!Z0 || !Y0 || N < 1 || z < 1 || z > 256) return b7_fail(c, B7_ERR_INVALID, "blr_fit: bad arguments");
+  if (!(alpha_prec > 0.0) || !(beta > 0.0)) return b7_fail(c, B7_ERR_INVALID, "blr_fit: precisions must be > 0");
+  B7_HIP(c, hipSetDevice(c->device));
+  c->fitted = false;
+  c->predicted = false;
+  const int zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  c->N = z;
+  c->Npad = zpad;
+  c->ycols = 1;
+  c->yld = 1;
+  c->mean = mean;
+  c->noise = 1.0 / beta;
+  c->amp = 0.0;
+  const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
+  B7_TRY(b7_ensure(c, c->K, nn));
+  B7_TRY(b7_ensure(c, c->L, nn));
+  B7_TRY(b7_ensure(c, c->Linv, nn));
+  const size_t wbytes = sizeof(double) * (np * np > np * (size_t)nk ? np * np : np * (size_t)nk);
+  B7_TRY(b7_ensure(c, c->W, wbytes));
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * np * nk));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np));
+  B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np));
+  B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)nk));
+  B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
+  // Z0' (zero padded to zpad x nk) and beta * (Y0 - mean)
+  std::vector<double> zt(np * nk, 0.0), rb((size_t)nk, 0.0);
+  for (int i = 0; i < N; ++i) {
+    for (int k = 0; k < z; ++k) zt[(size_t)k * nk + i] = Z0[(size_t)i * z + k];
+    rb[i] = beta * (Y0[i] - mean);
+  }
+  B7_HIP(c, hipMemcpyAsync(c->tmpgrid.p, zt.data(), sizeof(double) * np * nk, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipMemcpyAsync(c->tmpvar.p, rb.data(), sizeof(double) * nk, hipMemcpyHostToDevice, c->stream));
+  // G = Z0'Z0 (MFMA), K = beta G + alpha I, q = Z0' beta r
+  B7_TRY(launch_gemm_nt(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpgrid.p, nk, (double *)c->W.p, zpad,
+                        zpad, zpad, nk));
+  B7_TRY(launch_blr_assemble(c, (const double *)c->W.p, (double *)c->K.p, z, zpad, alpha_prec, beta));
+  B7_TRY(launch_gemv_rows(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpvar.p, nk, 0.0, 0, zpad, zpad,
+                          (double *)c->resid.p));
+  int info_first = 0;
+  double jitter = 0.0;
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first));
+  B7_TRY(launch_trtri(c));
+  B7_TRY(launch_alpha(c));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (nll_out) {
+    // -log p(y | alpha, beta) = -[ z/2 log alpha + N/2 log beta - E(m) - 1/2 log|K| - N/2 log 2 pi ],
+    // E(m) = beta/2 |r|^2 - 1/2 (beta q)' m     (Bishop 3.82 / 3.86)
+    std::vector<double> diag(z), m(z), bq(z);
+    B7_HIP(c, hipMemcpy2D(diag.data(), sizeof(double), c->L.p, sizeof(double) * (np + 1), sizeof(double), z,
+                          hipMemcpyDeviceToHost));
+    B7_HIP(c, hipMemcpy(m.data(), c->alpha.p, sizeof(double) * z, hipMemcpyDeviceToHost));
+    B7_HIP(c, hipMemcpy(bq.data(), c->resid.p, sizeof(double) * z, hipMemcpyDeviceToHost));
+    double logdet = 0.0, rr = 0.0, qm = 0.0;
+    for (int k = 0; k < z; ++k) {
+      logdet += 2.0 * log(diag[k]);
+      qm += bq[k] * m[k];
+    }
+    for (int i = 0; i < N; ++i) rr += (Y0[i] - mean) * (Y0[i] - mean);
+    const double Em = 0.5 * beta * rr - 0.5 * qm;
+    *nll_out = -(0.5 * z * log(alpha_prec) + 0.5 * N * log(beta) - Em - 0.5 * logdet - 0.5 * N * log(2.0 * M_PI));
+  }
+  c->model_kind = 1;
+  c->fitted = true;
+  return B7_OK;
+}
+
+int b7_blr_predict(b7_ctx *c, double *mean_host, double *var_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->fitted || c->model_kind != 1) return b7_fail(c, B7_ERR_STATE, "blr_predict: no Bayesian-linear fit");
+  if (c->Mfeat <= 0) return b7_fail(c, B7_ERR_STATE, "blr_predict: no features (b7_blr_basis / b7_blr_features)");
+  if (c->zdim != c->N) return b7_fail(c, B7_ERR_INVALID, "blr_predict: feature width %d != fit width %d", c->zdim, c->N);
+  if (c->Mfeat != c->M) return b7_fail(c, B7_ERR_STATE, "blr_predict: features are stale (the grid changed)");
+  B7_HIP(c, hipSetDevice(c->device));
+  const int64_t M = c->Mfeat;
+  B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)M));
+  B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)M));
+  const int64_t Mpad = round_up(M, B7_MROWS);
+  B7_TRY(launch_gemv_rows(c, (const double *)c->feat.p, c->Npad, (const double *)c->alpha.p, c->Npad, c->mean, 0, M, M,
+                          (double *)c->mu.p));
+  B7_TRY(launch_post(c, (const double *)c->feat.p, 0, Mpad, M, (double *)c->var.p));
+  c->predicted = true;
+  c->Mpred = M;
+  if (mean_host) B7_HIP(c, hipMemcpyAsync(mean_host, c->mu.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+  if (var_host) B7_HIP(c, hipMemcpyAsync(var_host, c->var.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+  if (mean_host || var_host) B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
 }
 

@@ -42,6 +42,7 @@ struct b7_ctx {
 
   // ---- fit state
   bool fitted = false;
+  int model_kind = 0;  // 0 = GP regressor, 1 = Bayesian linear head (DNGO): selects the predict path
   int N = 0, Npad = 0, dfit = 0, dpad = 0, ycols = 0;
   int yld = 1;   // leading dimension of alpha: 1 for one column, else ycols rounded up to 64 (zero padded)
   double amp = 0, noise = 0, mean = 0;
@@ -76,6 +77,11 @@ struct b7_ctx {
   DevBuf tmpgrid; // predict_at temporary grid
   DevBuf tmpmu, tmpvar;
   DevBuf fant;   // fantasize workspace (pending-point covariance pieces)
+  DevBuf feat;   // DNGO basis features of the resident grid: Mfeat x Npad (zero-padded columns)
+  int64_t Mfeat = 0;
+  int zdim = 0;
+  uint64_t feat_version = 0, grid_version = 0;
+  DevBuf netbuf; // MLP weights/biases of the basis network
 
   // ---- measurement
   hipEvent_t tev[B7_MAX_TIMERS][2];
@@ -151,6 +157,12 @@ int launch_fantasy_cov(b7_ctx *c, const double *kpp, const double *g, double *S,
 int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev);
 int launch_fantasy_sample(b7_ctx *c, const double *Lp, const double *mu, int P, int n, uint64_t seed, double *out);
 int launch_add_diag(b7_ctx *c, double *S, int ld, int n, double v);
+
+int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
+                       int n_layers, int activation, double *out, int ld_out);
+int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,
+                     int64_t rows, int64_t Mtotal, double *y);
+int launch_blr_assemble(b7_ctx *c, const double *G, double *K, int z, int zpad, double alpha_prec, double beta);
 
 // score.hip
 int launch_ei(b7_ctx *c, const double *mu, const double *var, const double *fmin_dev, double tradeoff,

@@ -96,7 +96,128 @@ __global__ void fantasy_sample_kernel(const double *__restrict__ Lp, const doubl
   out[e] = acc;
 }
 
+// ---- DNGO: basis network forward and the pieces of the Bayesian-linear head -------------------------------------------
+// Reference: models/dngo.lua:155-171 pushes X through `network` in minibatches and keeps `self.basis.output`
+// (the activations of the last hidden layer: nn.Linear / activation stacks from nnTools/builder.lua:118-151);
+// :174 hands those features to gp.models.bayes_linear (absent `gp` package), restated in api.hip.
+// One block = 32 inputs; activations ping-pong between two LDS buffers (dynamic, 2 x 32 x (maxw+1) doubles);
+// thread t computes units (t / 32 + 8 i) of input (t % 32).  Weights (row-major out x in, nn.Linear's layout, each
+// followed by its bias) stream from L2.
+constexpr int MLP_MAXW = 256;
+constexpr int MLP_IN = 32;
+__device__ __forceinline__ double mlp_act(double v, int kind) {
+  switch (kind) {
+    case 1: return tanh(v);
+    case 2: return v > 0.0 ? v : 0.0;
+    case 3: return 1.0 / (1.0 + exp(-v));
+    default: return v;
+  }
+}
+__global__ void __launch_bounds__(256)
+    mlp_forward_kernel(const double *__restrict__ X, int64_t M, int d, const double *__restrict__ net, int n_layers,
+                       int d0, int d1, int d2, int d3, int d4, int activation, int stride, double *__restrict__ out,
+                       int ld_out) {
+  extern __shared__ __align__(16) double msm[];
+  double *src = msm, *dst = msm + MLP_IN * stride;
+  const int dims[5] = {d0, d1, d2, d3, d4};
+  const int ci = threadIdx.x & (MLP_IN - 1), u0 = threadIdx.x / MLP_IN;
+  constexpr int UG = 256 / MLP_IN;
+  int64_t g = (int64_t)blockIdx.x * MLP_IN + ci;
+  const bool live = g < M;
+  if (!live) g = M - 1;
+  for (int k = u0; k < d; k += UG) src[ci * stride + k] = X[g * d + k];
+  __syncthreads();
+  const double *w = net;
+  for (int l = 0; l < n_layers; ++l) {
+    const int nin = dims[l], nout = dims[l + 1];
+    const double *bias = w + (size_t)nout * nin;
+    for (int o = u0; o < nout; o += UG) {
+      double s = bias[o];
+      const double *wr = w + (size_t)o * nin;
+      for (int k = 0; k < nin; ++k) s += wr[k] * src[ci * stride + k];
+      dst[ci * stride + o] = mlp_act(s, activation);
+    }
+    __syncthreads();
+    double *tmp = src;
+    src = dst;
+    dst = tmp;
+    w = bias + nout;
+  }
+  const int z = dims[n_layers];
+  if (live)
+    for (int k = u0; k < ld_out; k += UG) out[g * ld_out + k] = (k < z) ? src[ci * stride + k] : 0.0;
+}
+
+// y[row] = base + sum_k A[row][k] x[k]  (one wave per row)
+__global__ void __launch_bounds__(256)
+    gemv_rows_kernel(const double *__restrict__ A, int lda, const double *__restrict__ x, int n, double base,
+                     int64_t row0, int64_t Mtotal, double *__restrict__ y) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row0 + row >= Mtotal) return;
+  double s = 0.0;
+  for (int k = lane; k < n; k += 64) s += A[row * lda + k] * x[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) y[row0 + row] = base + s;
+}
+
+// K = beta * G + alpha_prec * I on the z x z corner, identity in the padding
+__global__ void blr_assemble_kernel(const double *__restrict__ G, double *__restrict__ K, int z, int zpad,
+                                    double alpha_prec, double beta) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= zpad * zpad) return;
+  const int i = e / zpad, j = e - i * zpad;
+  double v;
+  if (i < z && j < z) {
+    v = beta * G[e];
+    if (i == j) v = v + alpha_prec;
+  } else {
+    v = (i == j) ? 1.0 : 0.0;
+  }
+  K[e] = v;
+}
+
 }  // namespace
+
+int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
+                       int n_layers, int activation, double *out, int ld_out) {
+  PhaseScope ps(c, "basis");
+  if (n_layers < 1 || n_layers > 4) return b7_fail(c, B7_ERR_UNSUPPORTED, "mlp: 1..4 weighted layers supported");
+  int dd[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i <= n_layers; ++i) {
+    dd[i] = dims[i];
+    if (dims[i] < 1 || dims[i] > MLP_MAXW) return b7_fail(c, B7_ERR_UNSUPPORTED, "mlp: layer width %d > %d", dims[i], MLP_MAXW);
+  }
+  if (dims[0] != d) return b7_fail(c, B7_ERR_INVALID, "mlp: input width %d != grid dims %d", dims[0], d);
+  if (M <= 0) return B7_OK;
+  int maxw = 0;
+  for (int i = 0; i <= n_layers; ++i) maxw = dd[i] > maxw ? dd[i] : maxw;
+  const int stride = maxw + 1;
+  const int lds = 2 * MLP_IN * stride * (int)sizeof(double);
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((M + MLP_IN - 1) / MLP_IN)), dim3(256), lds, c->stream, X, M,
+                     d, net_dev, n_layers, dd[0], dd[1], dd[2], dd[3], dd[4], activation, stride, out, ld_out);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,
+                     int64_t rows, int64_t Mtotal, double *y) {
+  PhaseScope ps(c, "mean");
+  if (rows <= 0) return B7_OK;
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, A, lda, x, n, base,
+                     row0, Mtotal, y);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_blr_assemble(b7_ctx *c, const double *G, double *K, int z, int zpad, double alpha_prec, double beta) {
+  hipLaunchKernelGGL(blr_assemble_kernel, dim3((zpad * zpad + 255) / 256), dim3(256), 0, c->stream, G, K, z, zpad,
+                     alpha_prec, beta);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
 
 int launch_mean_multi(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *mu) {
   PhaseScope ps(c, "mean");

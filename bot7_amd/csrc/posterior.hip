@@ -27,7 +27,8 @@ namespace {
 template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI>
 __global__ void __launch_bounds__(64 * WM * WN, MINW)
     post_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0,
-                int64_t Mtotal, double amp, double var_add, int clamp, double var_min, double *__restrict__ var) {
+                int64_t Mtotal, double base, double sgn, double var_add, int clamp, double var_min,
+                double *__restrict__ var) {
   using GP = GemmF64<BM, BN, 16, WM, WN, false, PAD>;
   static_assert(GP::TM == 4 && GP::TN == 4, "64x64 per wave");
   extern __shared__ __align__(16) double sm[];
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MINW)
       double ss = red[threadIdx.x];
 #pragma unroll
       for (int w = 1; w < WM; ++w) ss += red[w * BN + threadIdx.x];
-      double v = (amp - ss) + var_add;
+      double v = (base + sgn * ss) + var_add;  // GP: amp - ss; Bayesian-linear head: 1/beta + ss
       if (clamp) v = (v < var_min) ? var_min : v;  // TH clamp: NaN passes through
       var[g] = v;
     }
@@ -80,9 +81,10 @@ int launch_post_variant(b7_ctx *c, const double *ks, int64_t row0, int64_t rows,
   auto kern = post_kernel<BM, BN, WM, WN, MINW, PAD, TRI>;
   const int lds = GP::LDS_BYTES;
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const bool blr = c->model_kind == 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)(rows / BN)), dim3(64 * WM * WN), lds, c->stream, (const double *)c->Linv.p,
-                     ks, c->Npad, row0, Mtotal, c->amp, c->opts.var_with_noise ? c->noise : 0.0, c->opts.var_clamp,
-                     c->opts.var_min, var);
+                     ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
+                     blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

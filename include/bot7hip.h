@@ -141,6 +141,35 @@ int b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, ui
 /* Inspection (tests): lower Cholesky factor N x N, alpha N x ycols, explicit inverse factor N x N. */
 int b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
 
+/* ---- model: bot7.models.dngo -- basis network + Bayesian linear head (models/dngo.lua:108-175) -------------- */
+
+/* The trained feature extractor as plain arrays: layer l is nn.Linear(dims[l], dims[l+1]) with W[l] row-major
+ * dims[l+1] x dims[l] (nn.Linear's weight layout) and bias b[l], each followed by the same activation
+ * (0 identity, 1 Tanh, 2 ReLU, 3 Sigmoid); the output of the last listed layer is the basis (self.basis.output,
+ * models/dngo.lua:101-105).  1..4 layers, widths <= 256.  Training the network (nnTools.trainer) is out of scope. */
+typedef struct {
+  int n_layers;
+  const int *dims;          /* n_layers + 1 entries */
+  const double *const *W;
+  const double *const *b;
+  int activation;
+} b7_mlp;
+
+/* models/dngo.lua:155-171: features by a forward pass.  X == NULL: the resident candidate grid, features stay on
+ * the device for b7_blr_predict (Z_host nullable, M ignored).  X != NULL: M x dims[0] host rows, Z_host M x z. */
+int b7_blr_basis(b7_ctx *ctx, const b7_mlp *net, const double *X, int64_t M, double *Z_host);
+/* Caller-made features for the candidates (M x z) instead of a grid + network. */
+int b7_blr_features(b7_ctx *ctx, const double *Z1, int64_t M, int z);
+/* gp.models.bayes_linear (absent `gp` package) restated as standard Bayesian linear regression (Bishop 3.3;
+ * Snoek et al. 2015): prior precision alpha_prec, noise precision beta, constant mean:
+ *   K = beta Z0'Z0 + alpha_prec I,  m = beta K^-1 Z0'(Y0 - mean).  Replaces the GP fit on this context.
+ * nll_out (nullable): negative log evidence, for sampling (alpha_prec, beta) on the host ('marginalize'). */
+int b7_blr_fit(b7_ctx *ctx, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta,
+               double mean, double *nll_out);
+/* mean = m0 + Z1 m, var = 1/beta + z' K^-1 z over the resident features; results stay on the device for the
+ * b7_score_* calls (same accumulator and arg-max as the GP path). */
+int b7_blr_predict(b7_ctx *ctx, double *mean_host, double *var_host);
+
 /* ---- scores: bot7.scores.expected_improvement / confidence_bound + bayesopt marginalisation ---- */
 
 /* bots/bayesopt.lua:69: score = zeros(M). */

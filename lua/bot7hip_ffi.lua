@@ -33,6 +33,11 @@ int  b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 int  b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_host, double *var_host);
 int  b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, uint64_t seed, double *Y_out, double *mean_out, double *cov_out);
 int  b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
+typedef struct { int n_layers; const int *dims; const double *const *W; const double *const *b; int activation; } b7_mlp;
+int  b7_blr_basis(b7_ctx *ctx, const b7_mlp *net, const double *X, int64_t M, double *Z_host);
+int  b7_blr_features(b7_ctx *ctx, const double *Z1, int64_t M, int z);
+int  b7_blr_fit(b7_ctx *ctx, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta, double mean, double *nll_out);
+int  b7_blr_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 int  b7_score_reset(b7_ctx *ctx);
 int  b7_score_ei(b7_ctx *ctx, const double *fmin, double tradeoff);
 int  b7_score_cb(b7_ctx *ctx, double tradeoff, int upper, double sign);

@@ -50,3 +50,12 @@ def make_problem(ctx_or_none, orc, d, N, M, objective, seed_skip=1):
     amp = float(np.var(Y))
     hyp = {"lenscale_sq": np.full(d, d / 8.0), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
     return X_obs, Y, X_hid, hyp
+
+
+def make_network(d, widths, seed=0):
+    """A fixed random 'trained' basis network: weights for nn.Linear(d, w1), nn.Linear(w1, w2), ..."""
+    rng = np.random.default_rng(seed)
+    dims = [d] + list(widths)
+    weights = [rng.normal(scale=1.0 / np.sqrt(dims[i]), size=(dims[i + 1], dims[i])) for i in range(len(widths))]
+    biases = [rng.normal(scale=0.1, size=dims[i + 1]) for i in range(len(widths))]
+    return weights, biases

@@ -525,3 +525,76 @@ def test_fantasize_moments_and_pending_ei(ctx, orc):
     want = orc.c.ei(mu2, var2, Y2.min(axis=0))
     assert got.shape == (700,) and np.allclose(got, want, rtol=1e-5, atol=1e-9)
     assert int(np.argmax(got)) == int(np.argmax(want))
+
+
+# ---- DNGO: basis network + Bayesian linear head (BASELINE config 5) -----------------------------
+def test_dngo_basis_and_blr_head_match_oracle(ctx, orc):
+    from oracle import blr
+    from conftest import make_network
+    import bot7_amd
+    for d, widths, act, N, M in [(6, (50, 50, 50), "Tanh", 80, 3000), (2, (100,), "ReLU", 24, 257),
+                                 (32, (64, 100), "Sigmoid", 300, 1000)]:
+        W, b = make_network(d, widths, seed=d)
+        X_obs, Y, X_hid, _ = make_problem(ctx, orc, d, N, M, {6: B.hartmann6, 2: B.braninhoo, 32: B.ackley}[d])
+        Z0 = ctx.blr_basis(W, b, act, X=X_obs)
+        Z0_o = blr.basis(X_obs, W, b, act)
+        assert np.allclose(Z0, Z0_o, rtol=1e-12, atol=1e-13)
+        alpha_p, beta, mean = 2.0, 1.0 / (1e-2 * float(np.var(Y))), float(np.mean(Y))
+        f = blr.fit(Z0_o, Y, alpha_p, beta, mean)
+        nll = ctx.blr_fit(Z0, Y, alpha_p, beta, mean, want_nll=True)
+        assert nll == pytest.approx(float(f["nll"]), rel=1e-9, abs=1e-7)
+        ctx.grid_upload(X_hid)
+        Z1 = ctx.blr_basis(W, b, act, download=True)       # features of the resident grid, kept on the device
+        assert np.allclose(Z1, blr.basis(X_hid, W, b, act), rtol=1e-12, atol=1e-13)
+        mu, var = ctx.blr_predict()
+        mu_o, var_o = blr.predict(f, blr.basis(X_hid, W, b, act))
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+        assert (var >= 1.0 / beta).all()
+        # scores reuse the GP path's accumulator and arg-max
+        ctx.score_reset()
+        ctx.score_ei([float(Y.min())], 0.0)
+        _, idx, ei = ctx.score_finish(1.0, download=True)
+        want = orc.c.ei(mu_o, var_o, [float(Y.min())])
+        assert np.allclose(ei, want, rtol=1e-5, atol=1e-10) and idx == orc.c.argmax_first(want)[0]
+        # caller-made features instead of grid + network
+        ctx.blr_features(blr.basis(X_hid, W, b, act))
+        mu2, var2 = ctx.blr_predict()
+        assert np.allclose(mu2, mu, rtol=1e-12, atol=1e-13) and np.allclose(var2, var, rtol=1e-11, atol=0)
+    # stale features are refused after the grid changes
+    ctx.grid_upload(X_hid)
+    ctx.blr_basis(W, b, act)
+    ctx.grid_remove(3)
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.blr_predict()
+
+
+def test_dngo_model_in_bayesopt_loop(ctx, orc):
+    """config 5 plumbing: models.dngo through bots.bayesopt (no marginalisation loop, bots/bayesopt.lua:65-66)."""
+    from oracle import blr
+    from conftest import make_network
+    import bot7_amd
+
+    class H(object):
+        def __init__(self, name):
+            self.name, self.min, self.max, self.size = name, 0.0, 1.0, 1
+
+    W, b = make_network(6, (50, 50, 50), seed=1)
+    cfg = {"bot": {"verbose": 0, "budget": 7, "nInitial": 3, "nSamples": 10, "seed": 3},
+           "grid": {"type": "sobol", "size": 2000, "dims": 6}, "score": {"type": "expected_improvement"},
+           "model": {"type": "dngo", "network": {"weights": W, "biases": b, "activation": "Tanh"}, "alpha": 1.0}}
+    grid = bot7_amd.grids.sobol(dict(cfg["grid"], mins=np.zeros(6), maxes=np.ones(6)), context=ctx)()
+    model = bot7_amd.models.dngo(cfg["model"], context=ctx)
+    bot = bot7_amd.bots.bayesopt(B.hartmann6, [H("x%d" % i) for i in range(6)], cfg,
+                                 cache={"candidates": grid, "model": model})
+    for t in range(1, 8):
+        cand = np.asarray(bot.candidates).copy()
+        obs = None if bot.observed is None else bot.observed.copy()
+        resp = None if bot.responses is None else bot.responses.copy()
+        x, y = bot.run_trial()
+        if t > 3:
+            h = model.hyp
+            f = blr.fit(blr.basis(obs, W, b, "Tanh"), resp, h["alpha"], h["beta"], h["mean"])
+            mu, var = blr.predict(f, blr.basis(cand, W, b, "Tanh"))
+            widx = orc.c.argmax_first(orc.c.ei(mu, var, [float(resp.min())]))[0]
+            assert np.array_equal(x, cand[widx - 1]), "trial %d nominated a different candidate" % t
+    assert bot.observed.shape == (7, 6)
