@@ -30,8 +30,11 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (d, N, default per-GPU M, objective, score)
     "metric": (32, 2048, 1 << 20, "ackley", "ei"),
+    "cfg4": (64, 2048, 262144, "rastrigin", "ei"),   # BASELINE config 4: 2M candidates over 8 GPUs; d = 64 is beyond
+                                                     # the reference's Sobol table (dims < 40) -> counter-based grid
     "cfg3": (32, 1024, 262144, "ackley", "ei"),
     "cfg2": (6, 256, 32768, "hartmann6", "cb"),
+    "cfg5": (5, 256, 65536, "dngo", "ei"),           # BASELINE config 5: DNGO head (3 x 50 tanh basis), 65536 candidates
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; measured 74.5-77.3 (profiles/r01_mfma_f64_probe.txt)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
@@ -45,6 +48,8 @@ def parse():
     ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
     ap.add_argument("--candidates", type=int, default=0, help="candidates per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo lets several ranks share one GPU (rehearsal of the N>1 path)")
     ap.add_argument("--cpu-sample", type=int, default=131072, help="candidates in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -105,10 +110,14 @@ def main():
 
     import torch
     import torch.distributed as td
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     grouped = "RANK" in os.environ  # launched by torch.distributed.run: join the group even when it has one rank
-    if grouped:
+    if grouped and args.backend == "nccl":
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif grouped:
+        td.init_process_group("gloo", rank=rank, world_size=world)
 
     import bot7_amd
     from bot7_amd import benchmarks, dist
@@ -120,24 +129,42 @@ def main():
     info = ctx.device_info()
 
     # ---- inputs, resident in HBM before the timed region
-    X_obs = ctx.grid_sobol(N, d, 1 + M_total)                      # the N points after the candidate range
-    Y = benchmarks.registry[obj_name](X_obs)
-    amp = float(np.var(Y))
-    hyp = {"lenscale_sq": np.full(d, d / 8.0), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
     shard = dist.ShardedScorer(ctx, M_total, rank, world)
-    shard.make_sobol(d, skip=1, download=False)
-    fmin = [float(Y.min())]
     dev = torch.device("cuda", local_rank)
+    if d < 40:
+        X_obs = ctx.grid_sobol(N, d, 1 + M_total)                  # the N points after the candidate range
+        shard.make_sobol(d, skip=1, download=False)
+    else:
+        X_obs = ctx.grid_random(N, d, seed=1, row_offset=M_total)  # same idea on the counter-based grid
+        shard.make_random(d, seed=1, download=False)
+    if obj_name == "dngo":                                         # config 5: synthetic trained basis + hartmann-like Y
+        rng = np.random.default_rng(0)
+        dims = [d, 50, 50, 50]
+        Wn = [rng.normal(scale=1.0 / np.sqrt(dims[i]), size=(dims[i + 1], dims[i])) for i in range(3)]
+        bn = [rng.normal(scale=0.1, size=dims[i + 1]) for i in range(3)]
+        Y = benchmarks.rastrigin(X_obs)
+        alpha_p, beta, ymean = 1.0, 1.0 / (1e-2 * float(np.var(Y))), float(np.mean(Y))
+    else:
+        Y = benchmarks.registry[obj_name](X_obs)
+        amp = float(np.var(Y))
+        hyp = {"lenscale_sq": np.full(d, d / 8.0), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
+    fmin = [float(Y.min())]
 
     def step():
-        ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
-        ctx.gp_predict(download=False)
+        if obj_name == "dngo":
+            Z0 = ctx.blr_basis(Wn, bn, "Tanh", X=X_obs)
+            ctx.blr_fit(Z0, Y, alpha_p, beta, ymean)
+            ctx.blr_basis(Wn, bn, "Tanh")
+            ctx.blr_predict(download=False)
+        else:
+            ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+            ctx.gp_predict(download=False)
         ctx.score_reset()
         if score == "ei":
             ctx.score_ei(fmin, 0.0)
         else:
             ctx.score_cb()
-        return shard.nominate(1.0, device=dev)
+        return shard.nominate(1.0, device=dev if args.backend == "nccl" else "cpu")
 
     def fence():
         ctx.sync()
@@ -158,12 +185,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 
     phases = {}
-    for ph in ("kxx", "potrf", "trtri", "alpha", "ksx", "post", "score", "argmax"):
+    for ph in ("kxx", "potrf", "trtri", "alpha", "basis", "mean", "ksx", "post", "score", "argmax"):
         ms, n = ctx.profile_get(ph)
         if n:
             phases[ph] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
@@ -173,7 +200,8 @@ def main():
     # exploited: N^2/2 multiply-adds per candidate); rows per launch = M / launches-per-step.
     post_launches_per_step = max(1, post["launches"] // max(1, args.steps))
     rows_per_launch = M / post_launches_per_step
-    flops_per_launch = rows_per_launch * float(N) * float(N)
+    n_eff = 128 if obj_name == "dngo" else N   # DNGO: the "observations" of the variance GEMM are the 50 -> 128 padded features
+    flops_per_launch = rows_per_launch * float(n_eff) * float(n_eff)
     post_avg_s = (post["ms_total"] / post["launches"] * 1e-3) if post["launches"] else float("nan")
     achieved = flops_per_launch / post_avg_s / 1e12 if post["launches"] else float("nan")
     ksx = phases.get("ksx")
@@ -191,9 +219,10 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %s d=%d, N=%d obs, %d Sobol candidates per GPU (%d total), %s, one hyper "
-                               "sample per step = GP fit + K(X*,X) + posterior mean/var + score + arg-max"
-                               % (args.workload, obj_name, d, N, M, M_total, score.upper()),
+        "config": {"workload": "%s: %s d=%d, N=%d obs, %d %s candidates per GPU (%d total), %s, one hyper "
+                               "sample per step = fit + K(X*,X) + posterior mean/var + score + arg-max"
+                               % (args.workload, obj_name, d, N, M, "Sobol" if d < 40 else "counter-based uniform",
+                                  M_total, score.upper()),
                    "d": d, "n_obs": N, "candidates_per_gpu": M, "candidates_total": M_total, "score": score,
                    "parallelism": "candidate-sharded x%d, fit replicated, one (value,index) RCCL exchange" % world,
                    "device": info["name"]},
@@ -212,7 +241,7 @@ def main():
         "phases": phases,
         "best": {"value": best[0], "index1": best[1]},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and obj_name != "dngo":
         line["cpu_baseline"] = cpu_baseline(d, N, obj_name, score, args.cpu_sample, X_obs, Y, hyp)
     elif rank == 0:
         line["cpu_baseline"] = None
