@@ -621,3 +621,89 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(ctx):
     b2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert b2["n_gpus"] == 2 and b2["config"]["candidates_total"] == 131072 == b1["config"]["candidates_total"]
     assert b1["best"] == b2["best"], "sharded winner differs from the unsharded arg-max"
+
+
+# ---- edge cases through the C ABI ---------------------------------------------------------------------------------
+def test_edge_shapes_and_options(ctx, orc):
+    import bot7_amd
+    rng = np.random.default_rng(17)
+    # N = 1, d = 1; M = 1
+    X = np.array([[0.3]])
+    Y = np.array([[1.5]])
+    ctx.gp_fit(X, Y, [0.25], 2.0, 1e-3, 0.5)
+    ctx.grid_upload(np.array([[0.31]]))
+    mu, var = ctx.gp_predict()
+    f = orc.gp.fit(X, Y, [0.25], 2.0, 1e-3, 0.5)
+    mu_o, var_o = orc.gp.predict(f, np.array([[0.31]]))
+    assert np.allclose(mu, mu_o, rtol=1e-9) and np.allclose(var, var_o, rtol=1e-6)
+    # every padded-dimension class boundary: d = 4|5, 8|9, 16|17, 32|33, 64|65, 96
+    for d in (4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 96):
+        N, M = 37, 130
+        Xo, Xh = rng.random((N, d)), rng.random((M, d))
+        Yo = np.sin(Xo.sum(1, keepdims=True))
+        ls = rng.random(d) * d + 0.1 * d
+        f = orc.gp.fit(Xo, Yo, ls, 1.3, 1e-3, 0.1)
+        ctx.gp_fit(Xo, Yo, ls, 1.3, 1e-3, 0.1)
+        ctx.grid_upload(Xh)
+        mu, var = ctx.gp_predict()
+        mu_o, var_o = orc.gp.predict(f, Xh)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL, "d = %d" % d
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        ctx.gp_fit(rng.random((5, 97)), np.zeros(5), np.ones(97), 1.0, 1e-3, 0.0)
+    assert e.value.code == -5                                    # d > 96: documented limit
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.gp_fit(rng.random((5, 3)), np.zeros((5, 257)), np.ones(3), 1.0, 1e-3, 0.0)  # ycols > 256
+    # options the `gp` package leaves open: noise in the predictive variance, clamping
+    Xo, Xh = rng.random((40, 3)), rng.random((500, 3))
+    Yo = np.cos(3 * Xo.sum(1, keepdims=True))
+    f = orc.gp.fit(Xo, Yo, [0.3] * 3, 1.0, 1e-2, 0.0)
+    ctx.gp_fit(Xo, Yo, [0.3] * 3, 1.0, 1e-2, 0.0)
+    ctx.grid_upload(Xh)
+    ctx.gp_set_opts(var_with_noise=1)
+    _, var_n = ctx.gp_predict()
+    _, var_on = orc.gp.predict(f, Xh, var_with_noise=True)
+    assert relerr(var_n, var_on) < REL
+    ctx.gp_set_opts(var_clamp=1, var_min=0.5)
+    _, var_c = ctx.gp_predict()
+    _, var_oc = orc.gp.predict(f, Xh, var_min=0.5)
+    assert np.allclose(var_c, var_oc, rtol=1e-5) and var_c.min() == 0.5
+    ctx.gp_set_opts()                                            # back to defaults
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.gp_set_opts(jitter_growth=1.0)
+    # NaN in a candidate propagates to its own mean/variance only (TH clamp passes NaN)
+    Xh2 = Xh.copy()
+    Xh2[7, 1] = np.nan
+    ctx.grid_upload(Xh2)
+    mu, var = ctx.gp_predict()
+    assert np.isnan(mu[7, 0]) and np.isnan(var[7]) and np.isfinite(np.delete(var, 7)).all()
+    ctx.score_reset()
+    ctx.score_ei([float(Yo.min())], 0.0)
+    _, idx, _ = ctx.score_finish(1.0)
+    assert idx == 8                                              # the first NaN wins score:max(1), as in TH
+
+
+def test_workspace_chunking_is_invisible(ctx, orc):
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 200, 5000, B.hartmann6)
+    ctx.gp_fit(X_obs, Y, **hyp)
+    ctx.grid_upload(X_hid)
+    mu, var = ctx.gp_predict()
+    for nbytes in (8 * 256 * 256, 8 * 256 * 300, 8 * 256 * 1024):   # 1, 1 and 4 tiles of 256 rows per chunk
+        ctx.set_workspace(nbytes)
+        mu2, var2 = ctx.gp_predict()
+        assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
+    ctx.set_workspace(4 << 30)
+    import bot7_amd
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.set_workspace(100)
+
+
+def test_sobol_random_shapes_property(ctx, orc):
+    """hypothesis: any (size, dims, skip) the reference accepts is reproduced bit for bit."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=30, deadline=None, derandomize=True)
+    @given(st.integers(1, 700), st.integers(1, 39), st.integers(0, 2 ** 13))  # the oracle walks the recurrence from 0
+    def check(size, dims, skip):
+        assert np.array_equal(ctx.grid_sobol(size, dims, skip), orc.c.sobol(size, dims, skip))
+
+    check()
