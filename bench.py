@@ -114,10 +114,28 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     grouped = "RANK" in os.environ  # launched by torch.distributed.run: join the group even when it has one rank
-    if grouped and args.backend == "nccl":
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    elif grouped:
-        td.init_process_group("gloo", rank=rank, world_size=world)
+    if grouped:
+        # RCCL prints a version banner on stdout when its communicator comes up (lazily, at the first collective):
+        # keep stdout for the one JSON line by pointing fd 1 at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                td.init_process_group("nccl", rank=rank, world_size=world,
+                                      device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+            else:
+                td.init_process_group("gloo", rank=rank, world_size=world)
+                warm = torch.zeros(1, dtype=torch.float64)
+            td.all_reduce(warm)
+            td.barrier()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import bot7_amd
     from bot7_amd import benchmarks, dist
