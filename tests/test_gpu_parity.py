@@ -707,3 +707,56 @@ def test_sobol_random_shapes_property(ctx, orc):
         assert np.array_equal(ctx.grid_sobol(size, dims, skip), orc.c.sobol(size, dims, skip))
 
     check()
+
+
+def test_full_size_cfg4_shape(ctx, orc):
+    """BASELINE config 4's per-GPU shape: rastrigin d = 64, N = 2048, counter-based uniform grid (Sobol stops at
+    39 dims in the reference), one 65536-row shard.  Sampled candidates against the oracle, determinism, bounds."""
+    d, N, M = 64, 2048, 65536
+    X_obs = ctx.grid_random(N, d, seed=1, row_offset=8 * M)
+    X_hid = ctx.grid_random(M, d, seed=1, row_offset=3 * M)        # shard 3 of 8
+    Y = B.rastrigin(X_obs)
+    amp = float(np.var(Y))
+    hyp = dict(lenscale_sq=np.full(d, d / 8.0), amp=amp, noise=1e-4 * amp, mean=float(np.mean(Y)))
+    ctx.gp_fit(X_obs, Y, **hyp)
+    mu, var = ctx.gp_predict()
+    mu_b, var_b = ctx.gp_predict()
+    assert np.array_equal(mu, mu_b) and np.array_equal(var, var_b)
+    assert (var > 0).all() and (var <= amp * (1 + 1e-12)).all()
+    f = orc.gp.fit(X_obs, Y, **hyp)
+    sample = np.random.default_rng(4).choice(M, 400, replace=False)
+    mu_o, var_o = orc.gp.predict(f, X_hid[sample])
+    assert relerr(mu[sample], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var[sample], var_o) < REL
+    ctx.score_reset()
+    ctx.score_ei([float(Y.min())], 0.0)
+    val, idx, ei = ctx.score_finish(1.0, download=True)
+    assert (idx, val) == orc.c.argmax_first(ei)
+
+
+def test_bench_contract():
+    """bench.py prints exactly one JSON line with the fields the driver and the judge read."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1",
+                        "--candidates", "262144", "--cpu-sample", "4096"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "EI candidates scored/sec at N=2048,d=32" and d["unit"] == "candidates/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.3 < rf["frac"] < 1.0
+    assert rf["traffic"] is not None and rf["traffic"] > rf["algorithmic_bytes_per_launch"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert d["value"] > 1e6, "below the north-star target of 1e6 candidates/s"
+    assert abs(d["value"] - d["config"]["candidates_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
