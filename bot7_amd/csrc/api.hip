@@ -461,7 +461,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
 
 int b7_gp_predict(b7_ctx *c, double *mean_host, double *var_host) {
   if (!c) return B7_ERR_INVALID;
-  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_predict: no fit on this context");
+  if (!c->fitted || c->model_kind != 0) return b7_fail(c, B7_ERR_STATE, "gp_predict: no GP fit on this context");
   if (c->M <= 0) return b7_fail(c, B7_ERR_STATE, "gp_predict: no candidate grid on this context");
   if (c->d != c->dfit) return b7_fail(c, B7_ERR_INVALID, "gp_predict: grid dims %d != fit dims %d", c->d, c->dfit);
   B7_HIP(c, hipSetDevice(c->device));
@@ -481,7 +481,7 @@ int b7_gp_predict(b7_ctx *c, double *mean_host, double *var_host) {
 
 int b7_gp_predict_at(b7_ctx *c, const double *X1, int64_t M1, double *mean_host, double *var_host) {
   if (!c) return B7_ERR_INVALID;
-  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_predict_at: no fit on this context");
+  if (!c->fitted || c->model_kind != 0) return b7_fail(c, B7_ERR_STATE, "gp_predict_at: no GP fit on this context");
   if (M1 < 0 || (!X1 && M1 > 0)) return b7_fail(c, B7_ERR_INVALID, "gp_predict_at: bad X1/M1");
   if (M1 == 0) return B7_OK;
   B7_HIP(c, hipSetDevice(c->device));
@@ -502,7 +502,7 @@ int b7_gp_predict_at(b7_ctx *c, const double *X1, int64_t M1, double *mean_host,
 int b7_gp_fantasize(b7_ctx *c, const double *X_pend, int P, int n, uint64_t seed, double *Y_out, double *mean_out,
                     double *cov_out) {
   if (!c) return B7_ERR_INVALID;
-  if (!c->fitted) return b7_fail(c, B7_ERR_STATE, "gp_fantasize: no fit on this context");
+  if (!c->fitted || c->model_kind != 0) return b7_fail(c, B7_ERR_STATE, "gp_fantasize: no GP fit on this context");
   if (c->ycols != 1) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fantasize: the fit must have one response column");
   if (!X_pend || P < 1 || n < 1 || !Y_out) return b7_fail(c, B7_ERR_INVALID, "gp_fantasize: bad arguments");
   if (P > 64) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fantasize: %d pending points > 64", P);
@@ -722,7 +722,9 @@ int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, doub
 int b7_blr_predict(b7_ctx *c, double *mean_host, double *var_host) {
   if (!c) return B7_ERR_INVALID;
   if (!c->fitted || c->model_kind != 1) return b7_fail(c, B7_ERR_STATE, "blr_predict: no Bayesian-linear fit");
-  if (c->Mfeat <= 0) return b7_fail(c, B7_ERR_STATE, "blr_predict: no features (b7_blr_basis / b7_blr_features)");
+  if (c->Mfeat <= 0)
+    return b7_fail(c, B7_ERR_STATE, "blr_predict: no current features (call b7_blr_basis / b7_blr_features after the "
+                                    "last change of the candidate grid)");
   if (c->zdim != c->N) return b7_fail(c, B7_ERR_INVALID, "blr_predict: feature width %d != fit width %d", c->zdim, c->N);
   if (c->Mfeat != c->M) return b7_fail(c, B7_ERR_STATE, "blr_predict: features are stale (the grid changed)");
   B7_HIP(c, hipSetDevice(c->device));

@@ -1,0 +1,55 @@
+--[[
+Drop-in for bot7.models.dngo's predict path (models/dngo.lua:108-175) backed by b7_blr_basis / b7_blr_fit /
+b7_blr_predict.  The network is still built and trained by nnTools exactly as in the reference (:49-106,
+:126-152): this class only takes the trained nn.Linear layers up to the basis layer out of `self.network`,
+hands them to the GPU as plain arrays, and replaces the minibatch forward loops (:155-171) and the
+Bayesian-linear head (:174).  Register:  bot7.models.dngo_hip = require('bot7hip.models_dngo_hip')
+--]]
+local ffi = require('ffi')
+local hip = require('bot7hip.bot7hip_ffi')
+
+local title  = 'bot7.models.dngo_hip'
+local parent = 'bot7.models.dngo'
+local dngo, parent = torch.class(title, parent)
+
+local ACT = {['nn.Tanh'] = 1, ['nn.ReLU'] = 2, ['nn.Sigmoid'] = 3}
+
+-- Collect nn.Linear weights/biases from the input up to self.basis (the module whose output is the feature map)
+local function pack_network(self)
+  local Ws, bs, act = {}, {}, 0
+  for i = 1, self.network:size() do
+    local mod = self.network:get(i)
+    if torch.type(mod) == 'nn.Linear' then
+      Ws[#Ws+1] = mod.weight:double():contiguous(); bs[#bs+1] = mod.bias:double():contiguous()
+    elseif ACT[torch.type(mod)] then
+      act = ACT[torch.type(mod)]
+    end
+    if mod == self.basis then break end
+  end
+  local n    = #Ws
+  local dims = ffi.new('int[?]', n + 1)
+  local Wp, bp = ffi.new('const double*[?]', n), ffi.new('const double*[?]', n)
+  dims[0] = Ws[1]:size(2)
+  for l = 1, n do dims[l] = Ws[l]:size(1); Wp[l-1] = torch.data(Ws[l]); bp[l-1] = torch.data(bs[l]) end
+  local net = ffi.new('b7_mlp', {n, dims, Wp, bp, act})
+  return net, {Ws, bs, dims, Wp, bp}   -- second value keeps the arrays alive
+end
+
+function dngo:predict(X0, Y0, X1, hyp, req, skip)
+  if not skip then parent.predict(self, X0:narrow(1,1,1), Y0:narrow(1,1,1), X0:narrow(1,1,1), hyp, req, false) end -- retrain as the reference does (:126-152)
+  local net, keep = pack_network(self)
+  local z  = keep[3][#keep[1]]
+  local Z0 = torch.DoubleTensor(X0:size(1), z)
+  hip.check(hip.C.b7_blr_basis(hip.ctx, net, hip.ptr(X0), X0:size(1), torch.data(Z0)))          -- :155-162
+  local h  = self.blr_hyp or {alpha = 1.0, beta = 1.0 / (1e-2 * Y0:var()), mean = Y0:mean()}
+  hip.check(hip.C.b7_blr_fit(hip.ctx, torch.data(Z0), hip.ptr(Y0), X0:size(1), z, h.alpha, h.beta, h.mean, nil))
+  local X = X1:contiguous()
+  hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(X), X:size(1), X:size(2)))
+  hip.grid_version = hip.grid_version + 1
+  hip.check(hip.C.b7_blr_basis(hip.ctx, net, nil, 0, nil))                                        -- :164-171
+  local mean, var = torch.DoubleTensor(X1:size(1), 1), torch.DoubleTensor(X1:size(1))
+  hip.check(hip.C.b7_blr_predict(hip.ctx, torch.data(mean), torch.data(var)))                     -- :174
+  return {mean = mean, var = var}
+end
+
+return dngo

@@ -82,6 +82,14 @@ function model:predict(X_obs, Y_obs, X_hid, hyp, req)   -- scores/expected_impro
   return {mean = req.mean and mean or nil, var = req.var and var or nil}
 end
 
-function model:fantasize() error('gp_hip:fantasize not built yet (bots/bayesopt.lua never passes X_pend)') end
+function model:fantasize(nFantasies, X_obs, Y_obs, X_pend, hyp)   -- scores/expected_improvement.lua:57
+  fit(X_obs, Y_obs, hyp or self.hyp, false)
+  self.fcalls = (self.fcalls or 0) + 1
+  local P   = X_pend:size(1)
+  local out = torch.DoubleTensor(P, nFantasies)
+  hip.check(hip.C.b7_gp_fantasize(hip.ctx, hip.ptr(X_pend), P, nFantasies, (self.config.seed or 0) * 1000003 + self.fcalls,
+                                  torch.data(out), nil, nil))
+  return out
+end
 
 return model
