@@ -36,7 +36,13 @@ local function pack_network(self)
 end
 
 function dngo:predict(X0, Y0, X1, hyp, req, skip)
-  if not skip then parent.predict(self, X0:narrow(1,1,1), Y0:narrow(1,1,1), X0:narrow(1,1,1), hyp, req, false) end -- retrain as the reference does (:126-152)
+  if not skip then   -- refresh the network on (X0, Y0) with nnTools.trainer, as the reference does before predicting (:126-152)
+    local trainer = require('bot7.nnTools.trainer')
+    if self.state.dfdx then self.state.dfdx:zero() end
+    trainer(self.network, {xr = X0, yr = Y0}, self.config.update,
+            {optimizer = self.optimizer, buffers = self.buffers, criterion = self.criterion, state = self.state})
+  end
+  self.network:evaluate()
   local net, keep = pack_network(self)
   local z  = keep[3][#keep[1]]
   local Z0 = torch.DoubleTensor(X0:size(1), z)
