@@ -19,7 +19,7 @@ ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
-    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_download",
+    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
@@ -93,6 +93,7 @@ def load():
         "b7_gp_predict": (i32, [vp, vp, vp]),
         "b7_gp_predict_at": (i32, [vp, vp, i64, vp, vp]),
         "b7_gp_fantasize": (i32, [vp, vp, i32, i32, C.c_uint64, vp, vp, vp]),
+        "b7_gp_append": (i32, [vp, vp, vp]),
         "b7_gp_download": (i32, [vp, vp, vp, vp]),
         "b7_blr_basis": (i32, [vp, C.POINTER(Mlp), vp, i64, vp]),
         "b7_blr_features": (i32, [vp, vp, i64, i32]),
@@ -143,6 +144,7 @@ class Context(object):
         self._h = h
         self.device_id = int(device_id)
         self.grid_version = 0  # bumped whenever the resident grid changes (DeviceGrid views compare against it)
+        self.fit_token = 0     # bumped by every call that replaces the fit (models check it before gp_append)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -250,6 +252,7 @@ class Context(object):
         self._ck(self._L.b7_gp_fit(self._h, _ptr(X), _ptr(Y), N, d, Y.shape[1], C.byref(hyp), _ptr(nll),
                                    C.byref(jit), C.byref(info)))
         self.ycols = Y.shape[1]
+        self.fit_token += 1
         return {"nll": nll, "jitter": jit.value, "info": info.value}
 
     def chol(self, src):
@@ -259,6 +262,7 @@ class Context(object):
         res = np.empty((n, n), dtype=np.float64)
         jit, info = C.c_double(), C.c_int()
         self._ck(self._L.b7_chol(self._h, _ptr(A), n, _ptr(res), C.byref(jit), C.byref(info)))
+        self.fit_token += 1
         return res, jit.value, info.value
 
     def gp_predict(self, download=True):
@@ -292,6 +296,12 @@ class Context(object):
         self._ck(self._L.b7_gp_fantasize(self._h, _ptr(Xp), P, int(nFantasies), int(seed) & (2 ** 64 - 1), _ptr(out),
                                          _ptr(mu), _ptr(cov)))
         return (out, mu, cov) if want_moments else out
+
+    def gp_append(self, x_new, y_new):
+        """Extend the current fit by one observation under the same hypers (O(N^2))."""
+        x = _f64(x_new).ravel()
+        y = _f64(y_new).ravel()
+        self._ck(self._L.b7_gp_append(self._h, _ptr(x), _ptr(y)))
 
     def gp_download(self, N, ycols=1):
         Lh = np.empty((N, N), dtype=np.float64)
@@ -341,6 +351,7 @@ class Context(object):
         self._ck(self._L.b7_blr_fit(self._h, _ptr(Z0), _ptr(Y0), Z0.shape[0], Z0.shape[1], float(alpha_prec),
                                     float(beta), float(mean), C.byref(nll) if want_nll else None))
         self.ycols = 1
+        self.fit_token += 1
         return nll.value if want_nll else None
 
     def blr_predict(self, download=True):

@@ -304,7 +304,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   c->noise = hyp->noise;
   c->mean = hyp->mean;
   const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
-  B7_TRY(b7_ensure(c, c->xobs, sizeof(double) * (size_t)N * d));
+  B7_TRY(b7_ensure(c, c->xobs, sizeof(double) * np * d));  // room for b7_gp_append up to Npad rows
   B7_TRY(b7_ensure(c, c->w, sizeof(double) * c->dpad));
   B7_TRY(b7_ensure(c, c->zsc, sizeof(double) * np * c->dpad));
   B7_TRY(b7_ensure(c, c->zss, sizeof(double) * np));
@@ -549,6 +549,46 @@ int b7_gp_fantasize(b7_ctx *c, const double *X_pend, int P, int n, uint64_t seed
   B7_TRY(launch_fantasy_sample(c, S, mu, P, n, seed, out));
   B7_HIP(c, hipMemcpyAsync(Y_out, out, sizeof(double) * (size_t)P * n, hipMemcpyDeviceToHost, c->stream));
   if (mean_out) B7_HIP(c, hipMemcpyAsync(mean_out, mu, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+int b7_gp_append(b7_ctx *c, const double *x_new, const double *y_new) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->fitted || c->model_kind != 0) return b7_fail(c, B7_ERR_STATE, "gp_append: no GP fit on this context");
+  if (!x_new || !y_new) return b7_fail(c, B7_ERR_INVALID, "gp_append: NULL argument");
+  if (c->N + 1 > c->Npad)
+    return b7_fail(c, B7_ERR_STATE, "gp_append: the padded factor is full (N = %d); refit with b7_gp_fit", c->N);
+  B7_HIP(c, hipSetDevice(c->device));
+  const int N = c->N, np = c->Npad, d = c->dfit, yc = c->ycols;
+  c->predicted = false;
+  // the new observation joins the observation set (raw row, scaled row, half norm, residual row)
+  B7_HIP(c, hipMemcpyAsync((double *)c->xobs.p + (size_t)N * d, x_new, sizeof(double) * d, hipMemcpyHostToDevice,
+                           c->stream));
+  std::vector<double> r(yc);
+  for (int k = 0; k < yc; ++k) r[k] = y_new[k] - c->mean;
+  B7_HIP(c, hipMemcpyAsync((double *)c->resid.p + (size_t)N * yc, r.data(), sizeof(double) * yc, hipMemcpyHostToDevice,
+                           c->stream));
+  double *ls_dev = (double *)c->scratch.p;  // lengthscales of the current fit
+  B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N + 1, d));
+  // k = K(x_new, [X; x_new]) through the covariance kernel (row 0 of a 64-row launch)
+  B7_TRY(b7_ensure(c, c->fant, sizeof(double) * ((size_t)64 * np + 3 * (size_t)np + (size_t)np * 16 + 64)));
+  double *krows = (double *)c->fant.p, *lvec = krows + (size_t)64 * np, *uvec = lvec + np, *part = uvec + np;
+  int *status_dev = (int *)(part + (size_t)np * 16);
+  B7_TRY(launch_ksx(c, (const double *)c->xobs.p + (size_t)N * d, 0, 64, 1, d, krows, nullptr, 1));
+  B7_TRY(launch_append_vectors(c, krows, lvec, uvec, part));
+  B7_TRY(launch_append_finalize(c, krows, lvec, uvec, status_dev));
+  int status = 0;
+  B7_HIP(c, hipMemcpyAsync(&status, status_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (status != 0) {
+    // roll the observation set back; the caller refits from scratch (jitter schedule included)
+    B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    return b7_fail(c, B7_ERR_STATE, "gp_append: the extended matrix is not positive definite; refit with b7_gp_fit");
+  }
+  c->N = N + 1;
+  B7_TRY(launch_alpha(c));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
 }

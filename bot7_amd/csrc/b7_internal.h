@@ -158,6 +158,8 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
 int launch_fantasy_sample(b7_ctx *c, const double *Lp, const double *mu, int P, int n, uint64_t seed, double *out);
 int launch_add_diag(b7_ctx *c, double *S, int ld, int n, double v);
 
+int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, const double *uvec, int *status_dev);
+int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part);
 int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
                        int n_layers, int activation, double *out, int ld_out);
 int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,

@@ -177,7 +177,61 @@ __global__ void blr_assemble_kernel(const double *__restrict__ G, double *__rest
   K[e] = v;
 }
 
+// ---- incremental fit: append one observation (same hypers) ----------------------------------------------------
+// With K' = [K k; k' kappa]:  L' = [L 0; l' lambda],  l = L^-1 k,  lambda^2 = kappa - l'l,
+//                             inv(L') = [inv(L) 0; -(inv(L)' l)'/lambda, 1/lambda].
+// One block: reduces l'l in a fixed order, then writes row/column N of K and row N of L and L^-1.
+// status[0] = 1 if lambda^2 is not positive (the caller then refits from scratch with the jitter schedule).
+__global__ void __launch_bounds__(256)
+    append_finalize_kernel(const double *__restrict__ krow, const double *__restrict__ lvec,
+                           const double *__restrict__ uvec, double noise, int N, int Npad, double *__restrict__ K,
+                           double *__restrict__ L, double *__restrict__ Linv, int *__restrict__ status) {
+  __shared__ double red[256];
+  __shared__ double lam_s;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) s += lvec[i] * lvec[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double kappa = krow[N] + noise;
+    const double l2 = kappa - red[0];
+    if (!(l2 > 0.0)) {
+      status[0] = 1;
+      lam_s = 0.0;
+    } else {
+      status[0] = 0;
+      lam_s = sqrt(l2);
+    }
+  }
+  __syncthreads();
+  const double lam = lam_s;
+  if (!(lam > 0.0)) return;
+  for (int j = threadIdx.x; j < Npad; j += 256) {
+    if (j < N) {
+      K[(int64_t)N * Npad + j] = krow[j];
+      K[(int64_t)j * Npad + N] = krow[j];
+      L[(int64_t)N * Npad + j] = lvec[j];
+      Linv[(int64_t)N * Npad + j] = -uvec[j] / lam;
+    } else if (j == N) {
+      K[(int64_t)N * Npad + N] = krow[N] + noise;
+      L[(int64_t)N * Npad + N] = lam;
+      Linv[(int64_t)N * Npad + N] = 1.0 / lam;
+    }
+  }
+}
+
 }  // namespace
+
+int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, const double *uvec, int *status_dev) {
+  hipLaunchKernelGGL(append_finalize_kernel, dim3(1), dim3(256), 0, c->stream, krow, lvec, uvec, c->noise, c->N,
+                     c->Npad, (double *)c->K.p, (double *)c->L.p, (double *)c->Linv.p, status_dev);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
 
 int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
                        int n_layers, int activation, double *out, int ld_out) {

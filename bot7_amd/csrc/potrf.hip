@@ -431,6 +431,26 @@ int launch_trtri(b7_ctx *c) {
   return B7_OK;
 }
 
+// l = Linv[0:nrows, 0:nrows] * k  and  u = Linv[0:nrows, 0:nrows]' * l   (the two mat-vecs of b7_gp_append;
+// rows >= nrows of the outputs are zeroed so that the padding row being replaced does not leak in)
+__global__ void zero_tail_kernel(double *__restrict__ v, int from, int n) {
+  const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = 0.0;
+}
+int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part) {
+  const int n = c->Npad, nrows = c->N;
+  hipLaunchKernelGGL(trmv_lower_kernel, dim3(n / 4), dim3(256), 0, c->stream, (const double *)c->Linv.p, krow, lvec, n,
+                     1);
+  hipLaunchKernelGGL(zero_tail_kernel, dim3((n - nrows + 255) / 256), dim3(256), 0, c->stream, lvec, nrows, n);
+  const int nslices = (n + TSL - 1) / TSL;
+  hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices), dim3(256), 0, c->stream,
+                     (const double *)c->Linv.p, (const double *)lvec, part, n, 1);
+  hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double *)part,
+                     uvec, n, nrows, 1, 1, nslices);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
 int launch_alpha(b7_ctx *c) {
   PhaseScope ps(c, "alpha");
   const int n = c->Npad;

@@ -135,10 +135,30 @@ class gp_regressor(abstract):
 
     # ---- posterior ---------------------------------------------------------------------------------
     def fit(self, X_obs, Y_obs, hyp=None):
+        """Fit on the device.  When the call is "the previous fit plus one observation, same hypers" (what
+        bots/abstract.lua:137-149 produces trial after trial under a point estimate), the factor is extended in
+        O(N^2) by b7_gp_append instead of being rebuilt (config.incremental, default True)."""
         hyp = hyp or self.hyp
         if hyp is None:
             hyp = self.init(X_obs, Y_obs)
-        self.last_fit = self.ctx.gp_fit(X_obs, Y_obs, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        X = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
+        Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
+        key = (tuple(np.asarray(hyp["lenscale_sq"], dtype=np.float64).ravel()), hyp["amp"], hyp["noise"], hyp["mean"])
+        prev = getattr(self, "_prev", None)
+        if (self.config.get("incremental", True) and prev is not None and prev["token"] == self.ctx.fit_token
+                and prev["key"] == key and X.shape[0] == prev["X"].shape[0] + 1 and Y.shape[1] == prev["Y"].shape[1]
+                and np.array_equal(X[:-1], prev["X"]) and np.array_equal(Y[:-1], prev["Y"])):
+            from .._lib import Bot7HipError
+            try:
+                self.ctx.gp_append(X[-1], Y[-1])
+                self._prev = {"token": self.ctx.fit_token, "key": key, "X": X.copy(), "Y": Y.copy()}
+                self.last_fit = {"nll": None, "jitter": 0.0, "info": 0, "incremental": True}
+                return self.last_fit
+            except Bot7HipError as e:
+                if e.code != -4:   # B7_ERR_STATE: factor full or not positive definite -> rebuild below
+                    raise
+        self.last_fit = self.ctx.gp_fit(X, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        self._prev = {"token": self.ctx.fit_token, "key": key, "X": X.copy(), "Y": Y.copy()}
         return self.last_fit
 
     def _is_resident(self, X1):

@@ -138,6 +138,12 @@ int b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_hos
 int b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, uint64_t seed, double *Y_out,
                     double *mean_out, double *cov_out);
 
+/* Incremental refit (bots/abstract.lua:137-144 appends one observation per trial): extends the CURRENT fit by one
+ * observation (x_new[d], y_new[ycols]) under the same hypers in O(N^2): l = L^-1 k, lambda^2 = kappa - l'l, new rows
+ * of L and L^-1, alpha recomputed.  Returns B7_ERR_STATE when the padded factor is full (N a multiple of 128) or
+ * lambda^2 <= 0 -- refit with b7_gp_fit then (which also applies the jitter schedule). */
+int b7_gp_append(b7_ctx *ctx, const double *x_new, const double *y_new);
+
 /* Inspection (tests): lower Cholesky factor N x N, alpha N x ycols, explicit inverse factor N x N. */
 int b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
 

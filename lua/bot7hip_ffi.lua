@@ -32,6 +32,7 @@ int  b7_chol(b7_ctx *ctx, const double *src_host, int n, double *res_host, doubl
 int  b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 int  b7_gp_predict_at(b7_ctx *ctx, const double *X1, int64_t M1, double *mean_host, double *var_host);
 int  b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, uint64_t seed, double *Y_out, double *mean_out, double *cov_out);
+int  b7_gp_append(b7_ctx *ctx, const double *x_new, const double *y_new);
 int  b7_gp_download(b7_ctx *ctx, double *L_host, double *alpha_host, double *Linv_host);
 typedef struct { int n_layers; const int *dims; const double *const *W; const double *const *b; int activation; } b7_mlp;
 int  b7_blr_basis(b7_ctx *ctx, const b7_mlp *net, const double *X, int64_t M, double *Z_host);

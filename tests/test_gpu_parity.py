@@ -760,3 +760,48 @@ def test_bench_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 1e6, "below the north-star target of 1e6 candidates/s"
     assert abs(d["value"] - d["config"]["candidates_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
+# ---- incremental refit ---------------------------------------------------------------------------------
+def test_gp_append_matches_full_refit(ctx, orc):
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 125, 900, B.hartmann6)
+    ctx.gp_fit(X_obs[:120], Y[:120], **hyp)
+    ctx.grid_upload(X_hid)
+    for n in range(120, 125):                                    # 120 -> 125 one observation at a time
+        ctx.gp_append(X_obs[n], Y[n])
+        f = orc.gp.fit(X_obs[:n + 1], Y[:n + 1], **hyp)
+        L, alpha, Linv = ctx.gp_download(n + 1)
+        assert np.allclose(L, f.L, rtol=1e-9, atol=1e-12)
+        assert np.allclose(Linv @ f.L, np.eye(n + 1), atol=1e-8)
+        assert relerr(alpha, f.alpha, floor=1e-3 * np.abs(f.alpha).max()) < 1e-6
+        mu, var = ctx.gp_predict()
+        mu_o, var_o = orc.gp.predict(f, X_hid)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+    # the padded factor is full at a multiple of 128: the call refuses and a rebuild is required
+    ctx.gp_fit(X_obs[:3], Y[:3], **hyp)
+    Xm = orc.c.sobol(130, 6, 5000)
+    Ym = B.hartmann6(Xm)
+    ctx.gp_fit(Xm[:128], Ym[:128], **hyp)
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        ctx.gp_append(Xm[128], Ym[128])
+    assert e.value.code == -4
+    # a duplicate of an existing observation with tiny noise is numerically singular: refused, fit left intact
+    ctx.gp_fit(X_obs[:50], Y[:50], hyp["lenscale_sq"], hyp["amp"], 0.0, hyp["mean"])
+    L0, a0, _ = ctx.gp_download(50)
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.gp_append(X_obs[7], Y[7])
+    L1, a1, _ = ctx.gp_download(50)
+    assert np.array_equal(L0, L1) and np.array_equal(a0, a1)
+    mu, var = ctx.gp_predict()
+    f = orc.gp.fit(X_obs[:50], Y[:50], hyp["lenscale_sq"], hyp["amp"], 0.0, hyp["mean"])
+    assert relerr(var, orc.gp.predict(f, X_hid)[1], floor=1e-9) < 1e-3   # noiseless: variance itself is tiny near data
+    # the model mirror uses it transparently under a point estimate
+    model = bot7_amd.models.gp_regressor({}, context=ctx)
+    model.hyp = hyp
+    model.fit(X_obs[:60], Y[:60])
+    assert not model.last_fit.get("incremental")
+    model.fit(X_obs[:61], Y[:61])
+    assert model.last_fit.get("incremental")
+    model.fit(X_obs[:62], Y[:62], dict(hyp, amp=hyp["amp"] * 1.1))   # hypers changed -> rebuild
+    assert not model.last_fit.get("incremental")
