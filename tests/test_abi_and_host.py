@@ -143,3 +143,12 @@ def test_slice_sampler_defaults_and_distribution():
     a = S(logp, np.zeros((1, 2)), {"seed": 9, "nSamples": 3})
     b = S(logp, np.zeros((1, 2)), {"seed": 9, "nSamples": 3})
     assert a.shape == (3, 2) and np.array_equal(a, b)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No silent fallback: without the shared library the loader raises instead of computing elsewhere."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_SO", os.path.join(ROOT, "bot7_amd", "no_such_libbot7hip.so"))
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        _lib.load()
+    assert "no CPU fallback" in str(e.value)
