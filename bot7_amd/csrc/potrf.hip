@@ -20,14 +20,20 @@
 #include "b7_internal.h"
 #include "gemm_f64.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace {
 
 constexpr int NB = B7_PANEL;  // 64
-using G64NT = GemmF64<64, 64, 16, 2, 2, false>;
-using G64NN = GemmF64<64, 64, 16, 2, 2, true>;
+// 32-deep LDS stages: measured with s_memtime stamps, every stage of these 64x64-tile products carries ~1900 cycles
+// of fixed cost (barrier + restage) next to 1024 cycles of MFMA per 16 of depth, so fewer, deeper stages win.
+using G64NT = GemmF64<64, 64, 32, 2, 2, false>;
+using G64NN = GemmF64<64, 64, 32, 2, 2, true>;
 
 // L <- block-lower part of K (upper 64x64 blocks zeroed).
 // `extra` (the jitter of this attempt) is added to the first nreal diagonal entries: src + eps*I.
@@ -230,8 +236,11 @@ __global__ void __launch_bounds__(256)
 // I >= J (lower tiles only; 1-D grid over exactly those tiles).  kb = 1 updates with one 64-wide panel, kb = 2
 // with two at once (K = 128): the big update is issued once per PAIR of panels, which doubles its work per launch
 // at the same tile count.  The C tile is fetched before the product so its latency hides under the MFMAs.
+template <bool STAMP>
 __global__ void __launch_bounds__(256, 2)
-    potrf_syrk_kernel(double *__restrict__ L, int ld, int kc0, int kb, int j0, int ncols, int nbt) {
+    potrf_syrk_kernel(double *__restrict__ L, int ld, int kc0, int kb, int j0, int ncols, int nbt,
+                      unsigned long long *__restrict__ stamps) {
+  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
   int J = j0, rem = blockIdx.x;
   for (int c = 0; c < ncols; ++c, ++J) {
     const int h = nbt - J;
@@ -251,7 +260,9 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cin[i][j][r] = cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)];
   d4_t acc[2][2] = {};
+  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
   G64NT::run(a, ld, b, ld, 0, kb * NB, acc, sm);
+  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -259,6 +270,7 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = cin[i][j][r] - acc[i][j][r];
+  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
 // Linv <- blockdiag(dinv), zero elsewhere.
@@ -395,8 +407,31 @@ int launch_potrf(b7_ctx *c, double extra) {
   auto syrk = [&](int kc0, int kb, int j0, int ncols) {
     int tiles = 0;
     for (int J = j0; J < j0 + ncols; ++J) tiles += nb - J;
-    if (tiles > 0)
-      hipLaunchKernelGGL(potrf_syrk_kernel, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb);
+    if (tiles <= 0) return;
+    if (getenv("B7_SYRK_STAMPS") && kb == 2 && kc0 == 0) {  // diagnostic: per-block phase times of the first big update
+      unsigned long long *st = (unsigned long long *)c->W.p;  // W is allocated by gp_fit (not by b7_chol)
+      hipLaunchKernelGGL(potrf_syrk_kernel<true>, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb, st);
+      std::vector<unsigned long long> h((size_t)tiles * 4);
+      (void)hipMemcpyAsync(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      unsigned long long t0 = ~0ull, t1 = 0;
+      double s01 = 0, s12 = 0, s23 = 0;
+      for (int b = 0; b < tiles; ++b) {
+        t0 = h[b * 4] < t0 ? h[b * 4] : t0;
+        t1 = h[b * 4 + 3] > t1 ? h[b * 4 + 3] : t1;
+        s01 += h[b * 4 + 1] - h[b * 4];
+        s12 += h[b * 4 + 2] - h[b * 4 + 1];
+        s23 += h[b * 4 + 3] - h[b * 4 + 2];
+      }
+      unsigned long long lastStart = 0;
+      for (int b = 0; b < tiles; ++b) lastStart = h[b * 4] > lastStart ? h[b * 4] : lastStart;
+      fprintf(stderr, "syrk stamps: %d blocks; first start -> last end %llu cycles; last block started +%llu; mean per block: "
+                      "setup+C-prefetch-issue %.0f, gemm %.0f, epilogue %.0f\n",
+              tiles, t1 - t0, lastStart - t0, s01 / tiles, s12 / tiles, s23 / tiles);
+      return;
+    }
+    hipLaunchKernelGGL(potrf_syrk_kernel<false>, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb,
+                       (unsigned long long *)nullptr);
   };
   for (int a = 0; a < nb; a += 2) {
     const int b = a + 1;
