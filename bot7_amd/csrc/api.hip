@@ -100,6 +100,10 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   if (const char *pv = getenv("B7_POST_VARIANT")) c->post_variant = atoi(pv);
   if (const char *pv = getenv("B7_KSX_ABLATE")) c->ksx_ablate = atoi(pv);
+  if (const char *pv = getenv("B7_POTRF_GROUP")) {
+    const int g = atoi(pv);
+    if (g >= 1 && g <= 8) c->potrf_group = g;
+  }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->pev[0]);
   if (e == hipSuccess) e = hipEventCreate(&c->pev[1]);

@@ -70,6 +70,8 @@ struct b7_ctx {
   bool acc_valid = false;
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
+  int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
+                         // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
   int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
   int post_variant = 7;  // tile/occupancy variant of post_kernel (B7_POST_VARIANT overrides; see posterior.hip)
   DevBuf part;   // argmax partials (value, index)
