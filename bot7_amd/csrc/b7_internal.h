@@ -16,7 +16,9 @@ constexpr int B7_MROWS = 256; // chunk rows are multiples of this (largest candi
 constexpr int B7_MAX_D = 96;  // LDS budget of the covariance kernel: (64 + 2*64) rows x (dpad+1) doubles <= 160 KiB
 
 // Padded input dimension: the covariance kernel is instantiated per class so its MFMA chain unrolls.
-static inline int b7_dpad_class(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 96; }
+static inline int b7_dpad_class(int d) {
+  return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : 96;
+}
 
 struct DevBuf {
   void *p = nullptr;

@@ -78,9 +78,11 @@ __device__ __forceinline__ double pair_swap(double v) {  // value held by lane ^
 // mu (nullable): mean + K* alpha for ycols == 1.  blockIdx.y splits the observations into gridDim.y equal
 // ranges of whole slabs (used for K(X,X), where there are few query rows; mu must then be null).
 constexpr int KQ = 64;  // query rows per block (16 per wave)
-constexpr int KO = 64;  // observation slab
+// observation slab: 64 rows, 32 for the wide classes so that two blocks still fit a CU's LDS
+// (measured at DPAD = 64 with 64-row slabs: 1 block/CU, 2.07 TB/s against 3.97 TB/s at DPAD = 32)
+__host__ __device__ constexpr int ksx_slab(int dpad) { return dpad >= 48 ? 32 : 64; }
 
-// DPAD = padded input dimension, one of the classes {4, 8, 16, 32, 64, 96} (b7_dpad_class): compile-time so that
+// DPAD = padded input dimension, one of the classes {4, 8, 16, 32, 48, 64, 96} (b7_dpad_class): compile-time so that
 // the MFMA chain over DPAD/4 k-steps unrolls and the query fragments stay in registers for the whole block.
 // ABLATE (diagnostic, B7_KSX_ABLATE): 0 = product; 1 = no stores; 2 = no exp; 3 = no MFMA.
 template <int DPAD, int ABLATE>
@@ -90,7 +92,9 @@ __global__ void __launch_bounds__(256)
                const double *__restrict__ alpha, double amp, double meanc, int Npad, double *__restrict__ out,
                double *__restrict__ mu) {
   extern __shared__ __align__(16) double sm[];
-  constexpr int dpad = DPAD, NCH = (DPAD + 7) / 8, KSTEPS = DPAD / 4;
+  constexpr int KO = ksx_slab(DPAD);
+  constexpr int TPR = 256 / KO;                       // staging threads per slab row
+  constexpr int dpad = DPAD, NCH = (DPAD / 2 + TPR - 1) / TPR, KSTEPS = DPAD / 4;
   constexpr int stride = DPAD + 1;  // odd: conflict-free for the fused ds_read2_b64 fragment reads (gemm_f64.h)
   (void)dpad_rt;
   double *sq = sm;                          // KQ x stride
@@ -101,14 +105,15 @@ __global__ void __launch_bounds__(256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int64_t qbase = row0 + (int64_t)blockIdx.x * KQ;
-  const int srow = tid >> 2, sq4 = tid & 3;  // staging: 4 threads per row
+  const int srow = tid / TPR, sq4 = tid % TPR;  // slab staging: TPR threads per row
+  const int qrow = tid >> 2, qq4 = tid & 3;     // query staging: 64 rows, 4 threads per row
   constexpr int half = DPAD >> 1;            // 16-byte chunks per row
 
   // query tile (zero-padded columns)
   {
-    int64_t g = qbase + srow;
+    int64_t g = qbase + qrow;
     if (g > Mtotal - 1) g = Mtotal - 1;
-    for (int k = sq4; k < dpad; k += 4) sq[srow * stride + k] = (k < d) ? xq[g * d + k] : 0.0;
+    for (int k = qq4; k < dpad; k += 4) sq[qrow * stride + k] = (k < d) ? xq[g * d + k] : 0.0;
   }
   const int nslab_total = Npad / KO;
   const int nslab = nslab_total / gridDim.y;
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(256)
     const double *src = zsc + (int64_t)(s * KO + srow) * dpad;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int kc = i * 4 + sq4;
+      const int kc = i * TPR + sq4;
       if (kc < half) pre[i] = *reinterpret_cast<const d2_t *>(src + 2 * kc);
     }
     if (tid < KO) {
@@ -132,7 +137,7 @@ __global__ void __launch_bounds__(256)
     double *dst = so + buf * KO * stride + srow * stride;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int kc = i * 4 + sq4;
+      const int kc = i * TPR + sq4;
       if (kc < half) {
         dst[2 * kc] = pre[i][0];
         dst[2 * kc + 1] = pre[i][1];
@@ -243,6 +248,7 @@ __global__ void __launch_bounds__(256)
 }
 
 size_t ksx_lds_bytes(int dpad) {
+  const int KO = ksx_slab(dpad);
   return sizeof(double) * ((size_t)(KQ + 2 * KO) * (dpad + 1) + 4 * KO + KQ);
 }
 
@@ -270,6 +276,7 @@ int ksx_dispatch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t M
     case 8: return ksx_launch<8>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
     case 16: return ksx_launch<16>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
     case 32: return ksx_launch<32>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
+    case 48: return ksx_launch<48>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
     case 64: return ksx_launch<64>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
     case 96: return ksx_launch<96>(c, grid, xq, row0, Mtotal, d, o, alpha, meanc, out, mu);
     default: return b7_fail(c, B7_ERR_UNSUPPORTED, "covariance kernel: dpad %d is not a built class", c->dpad);
@@ -299,7 +306,7 @@ int launch_prep_obs_aux(b7_ctx *c, const double *xobs, const double *ls_dev, int
 
 // K(Xq, Xobs-set) for an arbitrary observation set: rows x o.npad, no mean.
 int launch_k_generic(b7_ctx *c, const double *xq, int64_t rows, int64_t Mtotal, const ObsSet &o, double *out) {
-  if (rows % KQ || o.npad % KO) return b7_fail(c, B7_ERR_INVALID, "k_generic: extents not multiples of 64");
+  if (rows % KQ || o.npad % 64) return b7_fail(c, B7_ERR_INVALID, "k_generic: extents not multiples of 64");
   return ksx_dispatch(c, dim3((unsigned)(rows / KQ), 1), xq, 0, Mtotal, c->dfit, o, nullptr, 0.0, out, nullptr);
 }
 
@@ -318,7 +325,7 @@ int launch_kxx(b7_ctx *c, double diag_add) {
   const int Npad = c->Npad;
   // few query rows: split the observations over blockIdx.y so that the grid covers the chip
   int ny = 1;
-  while (ny < 16 && (Npad / KO) % (ny * 2) == 0 && (Npad / KQ) * ny < 2 * c->cus) ny *= 2;
+  while (ny < 16 && (Npad / 64) % (ny * 2) == 0 && (Npad / KQ) * ny < 2 * c->cus) ny *= 2;
   const ObsSet o{(const double *)c->zsc.p, (const double *)c->zss.p, Npad};
   B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, ny), (const double *)c->xobs.p, 0, c->N, c->dfit, o, nullptr, 0.0,
                       (double *)c->K.p, nullptr));

@@ -636,8 +636,8 @@ def test_edge_shapes_and_options(ctx, orc):
     f = orc.gp.fit(X, Y, [0.25], 2.0, 1e-3, 0.5)
     mu_o, var_o = orc.gp.predict(f, np.array([[0.31]]))
     assert np.allclose(mu, mu_o, rtol=1e-9) and np.allclose(var, var_o, rtol=1e-6)
-    # every padded-dimension class boundary: d = 4|5, 8|9, 16|17, 32|33, 64|65, 96
-    for d in (4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 96):
+    # every padded-dimension class boundary: d = 4|5, 8|9, 16|17, 32|33, 48|49, 64|65, 96
+    for d in (4, 5, 8, 9, 16, 17, 32, 33, 48, 49, 64, 65, 96):
         N, M = 37, 130
         Xo, Xh = rng.random((N, d)), rng.random((M, d))
         Yo = np.sin(Xo.sum(1, keepdims=True))
