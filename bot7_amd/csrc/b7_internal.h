@@ -13,7 +13,7 @@
 constexpr int B7_NPAD = 128;  // observations padded to a multiple of this (post kernel's n-tile)
 constexpr int B7_PANEL = 64;  // Cholesky panel width / small-GEMM tile
 constexpr int B7_MROWS = 256; // chunk rows are multiples of this (largest candidates-per-block of any post variant)
-constexpr int B7_MAX_D = 96;  // LDS budget of the covariance kernel: (64 + 2*64) rows x (dpad+1) doubles <= 160 KiB
+constexpr int B7_MAX_D = 96;  // LDS budget of the covariance kernel: (64 + 2*32) rows x (dpad+1) doubles at dpad = 96
 
 // Padded input dimension: the covariance kernel is instantiated per class so its MFMA chain unrolls.
 static inline int b7_dpad_class(int d) {

@@ -7,10 +7,11 @@
 //   mean part of model:predict (scores/expected_improvement.lua:63): mu = m + K(X*,X) alpha
 //
 // Layout: the inner product X (Z' .* w) runs on v_mfma_f64_16x16x4_f64 with the query rows as the A operand
-// and the pre-scaled observations (z .* w, zero-padded to dpad = 4*ceil(d/4)) as B.  A block owns 64 query
-// rows and walks observations in slabs of 64 (double-buffered in LDS, next slab prefetched into registers while
-// the current one is consumed, one barrier per slab), so it sees whole rows of K(X*,X): the posterior-mean dot
-// product with alpha is accumulated in registers on the way and needs no second pass over K*.
+// and the pre-scaled observations (z .* w, zero-padded to the class dpad in {4,8,16,32,48,64,96}) as B.  A block
+// owns 64 query rows and walks observations in slabs of 64 (32 for dpad >= 48), double-buffered in LDS with the
+// next slab prefetched into registers while the current one is consumed (one barrier per slab), so it sees whole
+// rows of K(X*,X): the posterior-mean dot product with alpha is accumulated in registers on the way and needs no
+// second pass over K*.
 // Epilogue per element: arg = (c - xs/2) - zs/2 (the reference's ((-2c + xs) + zs) scaled by the exact factor
 // -1/2, same rounding points), clamp to <= 0 (NaN passes, as TH's clamp), amp * exp(arg).  Lane pairs swap one
 // value (DPP quad_perm) so every lane stores 16 bytes: 2 stores per 16x16 tile instead of 4.
@@ -18,7 +19,8 @@
 //
 // Priced by ablation on MI355X (tools/ksx_ab.py, 262144 x 2048, d = 32) before this structure: full 2.09 ms,
 // without stores 1.49, without exp 2.02, without MFMA 1.74 -> the old kernel was bound by its own staging
-// (integer division per element, two barriers per slab, no prefetch), not by arithmetic or HBM.
+// (integer division per element, two barriers per slab, no prefetch), not by arithmetic or HBM.  Now 1.06 ms =
+// 4.0 TB/s (51 % of HBM peak) at d = 32; 58 % at d <= 6, 40 % at d = 39, 32 % at d = 64 (tools/ksx_rate.py).
 #include "b7_internal.h"
 #include "gemm_f64.h"
 

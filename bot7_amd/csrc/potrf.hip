@@ -12,7 +12,9 @@
 // Structure (all extents padded to multiples of 64/128 by the caller; padding = identity):
 //   per 64-wide panel p:  diag   one workgroup factors the 64x64 diagonal block in LDS and inverts it
 //                         trsm   L21 = A21 * inv(L11)'            (MFMA, one 64x64 tile per workgroup)
-//                         syrk   A22 -= L21 L21'  lower tiles     (MFMA: the trailing update)
+//   per group of G = 2 panels:  syrk   narrow update of the next panel's block column inside the group (K = 64),
+//                         then ONE update A22 -= L21 L21' of everything right of the group with K = 64 G
+//                         (MFMA, 1-D grid over the lower tiles: the trailing update)
 //   inverse of L by recursive doubling over block size s = 64,128,...: for each pair [A 0; B C] of
 //   already-inverted diagonal blocks, X = -inv(C) * (B * inv(A)); two batched MFMA GEMMs per level.
 // The explicit inverse is what lets the posterior variance be one GEMM with a fused column sum of squares

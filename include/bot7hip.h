@@ -108,7 +108,7 @@ int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
  * scores/confidence_bound.lua:63): K = amp*exp(-pdist(X,X,lenscale_sq)/2) + noise*I with the distance of
  * utils/math.lua:65-111; L = chol(K) with the jitter schedule of utils/math.lua:159-218 (eps <- eps*growth
  * added to the ORIGINAL diagonal until success, or chol(I) once eps > ||K||_F); alpha = K^-1 (Y - mean).
- * X_obs N x d, Y_obs N x ycols (ycols <= 256: fantasy columns share K, L and differ only in alpha).
+ * X_obs N x d (d <= 96), Y_obs N x ycols (ycols <= 256: fantasy columns share K, L and differ only in alpha).
  * Outputs (all nullable): nll_out[ycols] negative log marginal likelihood,
  * jitter_used (0 = none, -1 = fell back to chol(I)), info = 1-based first failing pivot of the FIRST
  * attempt (0 = positive definite). */
