@@ -9,6 +9,8 @@
 // b7_gp_opts.var_with_noise).  torch.randn's stream is not part of the reference: z comes from a documented
 // counter-based generator (splitmix64 -> Box-Muller).
 #include "b7_internal.h"
+#include <stdlib.h>
+
 #include "gemm_f64.h"
 
 namespace {
@@ -148,6 +150,69 @@ __global__ void __launch_bounds__(256)
     for (int k = u0; k < ld_out; k += UG) out[g * ld_out + k] = (k < z) ? src[ci * stride + k] : 0.0;
 }
 
+// MFMA version for widths <= 128 (the usual DNGO shapes): a block owns 32 inputs; activations ping-pong in LDS
+// ([32][stride], odd stride, zero-padded to multiples of 4 in K and 16 in N); each layer's weights are staged through
+// LDS 64 output units at a time ([64][stride]); wave w computes M-tile (w & 1) x N-tiles 2 (w >> 1) + {0, 1} of the
+// chunk as act (A operand, [m][k]) times W' (B operand, W is [n][k]); epilogue adds the bias, applies the
+// activation and writes the next layer's input (padding columns written as zeros).
+__global__ void __launch_bounds__(256)
+    mlp_forward_mfma_kernel(const double *__restrict__ X, int64_t M, int d, const double *__restrict__ net,
+                            int n_layers, int d0, int d1, int d2, int d3, int d4, int activation, int stride,
+                            double *__restrict__ out, int ld_out) {
+  extern __shared__ __align__(16) double msm[];
+  double *src = msm, *dst = msm + 32 * stride, *wl = msm + 64 * stride;  // wl: [64][stride]
+  const int dims[5] = {d0, d1, d2, d3, d4};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int64_t g0 = (int64_t)blockIdx.x * 32;
+  // input rows, zero padded to a multiple of 4 columns
+  const int kin0 = (d + 3) & ~3;
+  for (int e = tid; e < 32 * kin0; e += 256) {
+    const int r = e / kin0, k = e - r * kin0;
+    int64_t g = g0 + r;
+    if (g > M - 1) g = M - 1;
+    src[r * stride + k] = (k < d) ? X[g * d + k] : 0.0;
+  }
+  const double *w = net;
+  for (int l = 0; l < n_layers; ++l) {
+    const int nin = dims[l], nout = dims[l + 1];
+    const int kpad = (nin + 3) & ~3, npad = (nout + 15) & ~15;
+    const double *bias = w + (size_t)nout * nin;
+    for (int n0 = 0; n0 < npad; n0 += 64) {
+      __syncthreads();  // src complete (first chunk) / previous chunk's wl consumed
+      for (int e = tid; e < 64 * kpad; e += 256) {
+        const int r = e / kpad, k = e - r * kpad;
+        wl[r * stride + k] = (n0 + r < nout && k < nin) ? w[(size_t)(n0 + r) * nin + k] : 0.0;
+      }
+      __syncthreads();
+      const int mt = wave & 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int nt = (wave >> 1) * 2 + t;
+        if (n0 + nt * 16 >= npad) continue;
+        d4_t c = {0.0, 0.0, 0.0, 0.0};
+        const double *pa = src + (mt * 16 + lr) * stride + lq;
+        const double *pb = wl + (nt * 16 + lr) * stride + lq;
+        for (int k4 = 0; k4 < kpad; k4 += 4) c = mfma_f64(pa[k4], pb[k4], c);
+        const int col = n0 + nt * 16 + lr;
+        const double bv = (col < nout) ? bias[col] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dst[(mt * 16 + lq + 4 * r) * stride + col] = (col < nout) ? mlp_act(c[r] + bv, activation) : 0.0;
+      }
+    }
+    __syncthreads();
+    double *tmp = src;
+    src = dst;
+    dst = tmp;
+    w = bias + nout;
+  }
+  const int z = dims[n_layers];
+  for (int e = tid; e < 32 * ld_out; e += 256) {
+    const int r = e / ld_out, k = e - r * ld_out;
+    if (g0 + r < M) out[(g0 + r) * ld_out + k] = (k < z) ? src[r * stride + k] : 0.0;
+  }
+}
+
 // y[row] = base + sum_k A[row][k] x[k]  (one wave per row)
 __global__ void __launch_bounds__(256)
     gemv_rows_kernel(const double *__restrict__ A, int lda, const double *__restrict__ x, int n, double base,
@@ -246,6 +311,16 @@ int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const doubl
   if (M <= 0) return B7_OK;
   int maxw = 0;
   for (int i = 0; i <= n_layers; ++i) maxw = dd[i] > maxw ? dd[i] : maxw;
+  if (maxw <= 128 && !getenv("B7_MLP_SCALAR")) {  // MFMA path
+    const int stride = ((maxw + 15) & ~15) + 1;
+    const int lds = (64 + 64) * stride * (int)sizeof(double);
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_mfma_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(mlp_forward_mfma_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), lds, c->stream, X, M, d,
+                       net_dev, n_layers, dd[0], dd[1], dd[2], dd[3], dd[4], activation, stride, out, ld_out);
+    B7_HIP(c, hipGetLastError());
+    return B7_OK;
+  }
   const int stride = maxw + 1;
   const int lds = 2 * MLP_IN * stride * (int)sizeof(double);
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_kernel),
