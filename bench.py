@@ -173,8 +173,7 @@ def main():
 
     def step():
         if obj_name == "dngo":
-            Z0 = ctx.blr_basis(Wn, bn, "Tanh", X=X_obs)
-            ctx.blr_fit(Z0, Y, alpha_p, beta, ymean)
+            ctx.blr_fit_x(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean)
             ctx.blr_basis(Wn, bn, "Tanh")
             ctx.blr_predict(download=False)
             ctx.score_reset()

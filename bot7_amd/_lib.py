@@ -20,7 +20,7 @@ SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
-    "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
+    "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
 
@@ -98,6 +98,7 @@ def load():
         "b7_blr_basis": (i32, [vp, C.POINTER(Mlp), vp, i64, vp]),
         "b7_blr_features": (i32, [vp, vp, i64, i32]),
         "b7_blr_fit": (i32, [vp, vp, vp, i32, i32, dbl, dbl, dbl, C.POINTER(dbl)]),
+        "b7_blr_fit_x": (i32, [vp, C.POINTER(Mlp), vp, vp, i32, dbl, dbl, dbl, C.POINTER(dbl)]),
         "b7_blr_predict": (i32, [vp, vp, vp]),
         "b7_score_reset": (i32, [vp]),
         "b7_score_ei": (i32, [vp, vp, dbl]),
@@ -350,6 +351,18 @@ class Context(object):
         nll = C.c_double()
         self._ck(self._L.b7_blr_fit(self._h, _ptr(Z0), _ptr(Y0), Z0.shape[0], Z0.shape[1], float(alpha_prec),
                                     float(beta), float(mean), C.byref(nll) if want_nll else None))
+        self.ycols = 1
+        self.fit_token += 1
+        return nll.value if want_nll else None
+
+    def blr_fit_x(self, weights, biases, activation, X0, Y0, alpha_prec, beta, mean=0.0, want_nll=False):
+        """Basis features of X0 and the Bayesian-linear fit in one device-side call."""
+        net = self._mlp(weights, biases, activation)
+        X0 = _f64(X0)
+        Y0 = _f64(Y0).ravel()
+        nll = C.c_double()
+        self._ck(self._L.b7_blr_fit_x(self._h, C.byref(net), _ptr(X0), _ptr(Y0), X0.shape[0], float(alpha_prec),
+                                      float(beta), float(mean), C.byref(nll) if want_nll else None))
         self.ycols = 1
         self.fit_token += 1
         return nll.value if want_nll else None

@@ -693,15 +693,11 @@ int b7_blr_features(b7_ctx *c, const double *Z1, int64_t M, int z) {
   return B7_OK;
 }
 
-int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta,
-               double mean, double *nll_out) {
-  if (!c) return B7_ERR_INVALID;
-  if (!Z0 || !Y0 || N < 1 || z < 1 || z > 256) return b7_fail(c, B7_ERR_INVALID, "blr_fit: bad arguments");
-  if (!(alpha_prec > 0.0) || !(beta > 0.0)) return b7_fail(c, B7_ERR_INVALID, "blr_fit: precisions must be > 0");
-  B7_HIP(c, hipSetDevice(c->device));
-  c->fitted = false;
-  c->predicted = false;
+// Shared tail of the two fit entry points: c->tmpgrid holds Z0' (zpad x nk, zero padded) on the device.
+static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_prec, double beta, double mean,
+                        double *nll_out) {
   const int zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
   c->N = z;
   c->Npad = zpad;
   c->ycols = 1;
@@ -709,25 +705,17 @@ int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, doub
   c->mean = mean;
   c->noise = 1.0 / beta;
   c->amp = 0.0;
-  const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->K, nn));
   B7_TRY(b7_ensure(c, c->L, nn));
   B7_TRY(b7_ensure(c, c->Linv, nn));
-  const size_t wbytes = sizeof(double) * (np * np > np * (size_t)nk ? np * np : np * (size_t)nk);
-  B7_TRY(b7_ensure(c, c->W, wbytes));
-  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * np * nk));
+  B7_TRY(b7_ensure(c, c->W, nn));
   B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
   B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np));
   B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)nk));
   B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
-  // Z0' (zero padded to zpad x nk) and beta * (Y0 - mean)
-  std::vector<double> zt(np * nk, 0.0), rb((size_t)nk, 0.0);
-  for (int i = 0; i < N; ++i) {
-    for (int k = 0; k < z; ++k) zt[(size_t)k * nk + i] = Z0[(size_t)i * z + k];
-    rb[i] = beta * (Y0[i] - mean);
-  }
-  B7_HIP(c, hipMemcpyAsync(c->tmpgrid.p, zt.data(), sizeof(double) * np * nk, hipMemcpyHostToDevice, c->stream));
+  std::vector<double> rb((size_t)nk, 0.0);
+  for (int i = 0; i < N; ++i) rb[i] = beta * (Y0[i] - mean);
   B7_HIP(c, hipMemcpyAsync(c->tmpvar.p, rb.data(), sizeof(double) * nk, hipMemcpyHostToDevice, c->stream));
   // G = Z0'Z0 (MFMA), K = beta G + alpha I, q = Z0' beta r
   B7_TRY(launch_gemm_nt(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpgrid.p, nk, (double *)c->W.p, zpad,
@@ -761,6 +749,47 @@ int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, doub
   c->model_kind = 1;
   c->fitted = true;
   return B7_OK;
+}
+
+int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta,
+               double mean, double *nll_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!Z0 || !Y0 || N < 1 || z < 1 || z > 256) return b7_fail(c, B7_ERR_INVALID, "blr_fit: bad arguments");
+  if (!(alpha_prec > 0.0) || !(beta > 0.0)) return b7_fail(c, B7_ERR_INVALID, "blr_fit: precisions must be > 0");
+  B7_HIP(c, hipSetDevice(c->device));
+  c->fitted = false;
+  c->predicted = false;
+  const int zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
+  std::vector<double> zt((size_t)zpad * nk, 0.0);  // Z0' (a layout change, no arithmetic)
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < z; ++k) zt[(size_t)k * nk + i] = Z0[(size_t)i * z + k];
+  B7_HIP(c, hipMemcpyAsync(c->tmpgrid.p, zt.data(), sizeof(double) * (size_t)zpad * nk, hipMemcpyHostToDevice,
+                           c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return blr_fit_core(c, Y0, N, z, alpha_prec, beta, mean, nll_out);
+}
+
+int b7_blr_fit_x(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec,
+                 double beta, double mean, double *nll_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!X0 || !Y0 || N < 1) return b7_fail(c, B7_ERR_INVALID, "blr_fit_x: bad arguments");
+  if (!(alpha_prec > 0.0) || !(beta > 0.0)) return b7_fail(c, B7_ERR_INVALID, "blr_fit_x: precisions must be > 0");
+  B7_HIP(c, hipSetDevice(c->device));
+  c->fitted = false;
+  c->predicted = false;
+  int z = 0;
+  B7_TRY(upload_net(c, net, &z));
+  if (z > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
+  const int d = net->dims[0], zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * ((size_t)N * d + (size_t)N * z)));
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
+  double *xdev = (double *)c->tmpmu.p, *zdev = xdev + (size_t)N * d;
+  B7_HIP(c, hipMemcpyAsync(xdev, X0, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_mlp_forward(c, xdev, N, d, (const double *)c->netbuf.p, net->dims, net->n_layers, net->activation,
+                            zdev, z));
+  B7_TRY(launch_transpose_pad(c, zdev, N, z, z, (double *)c->tmpgrid.p, zpad, nk));
+  return blr_fit_core(c, Y0, N, z, alpha_prec, beta, mean, nll_out);
 }
 
 int b7_blr_predict(b7_ctx *c, double *mean_host, double *var_host) {

@@ -168,6 +168,7 @@ int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const doubl
                        int n_layers, int activation, double *out, int ld_out);
 int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,
                      int64_t rows, int64_t Mtotal, double *y);
+int launch_transpose_pad(b7_ctx *c, const double *Z, int n, int ldz, int z, double *Zt, int zpad, int nk);
 int launch_blr_assemble(b7_ctx *c, const double *G, double *K, int z, int zpad, double alpha_prec, double beta);
 
 // score.hip

@@ -226,6 +226,15 @@ __global__ void __launch_bounds__(256)
   if (lane == 0) y[row0 + row] = base + s;
 }
 
+// Zt[k][i] = Z[i][k] (Z: n x ldz row-major, Zt: zpad x nk, zero padded) -- the layout gemm_nt wants for Z'Z
+__global__ void transpose_pad_kernel(const double *__restrict__ Z, int n, int ldz, int z, double *__restrict__ Zt,
+                                     int zpad, int nk) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= zpad * nk) return;
+  const int k = e / nk, i = e - k * nk;
+  Zt[e] = (k < z && i < n) ? Z[(int64_t)i * ldz + k] : 0.0;
+}
+
 // K = beta * G + alpha_prec * I on the z x z corner, identity in the padding
 __global__ void blr_assemble_kernel(const double *__restrict__ G, double *__restrict__ K, int z, int zpad,
                                     double alpha_prec, double beta) {
@@ -337,6 +346,13 @@ int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n
   if (rows <= 0) return B7_OK;
   hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, A, lda, x, n, base,
                      row0, Mtotal, y);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_transpose_pad(b7_ctx *c, const double *Z, int n, int ldz, int z, double *Zt, int zpad, int nk) {
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((zpad * nk + 255) / 256), dim3(256), 0, c->stream, Z, n, ldz, z, Zt,
+                     zpad, nk);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

@@ -62,8 +62,9 @@ class dngo(abstract):
 
     def fit(self, X_obs, Y_obs, hyp=None, want_nll=False):
         hyp = hyp or self.hyp or self.init(X_obs, Y_obs)
-        Z0 = self.basis(np.atleast_2d(np.asarray(X_obs, dtype=np.float64)))
-        return self.ctx.blr_fit(Z0, Y_obs, hyp["alpha"], hyp["beta"], hyp["mean"], want_nll=want_nll)
+        return self.ctx.blr_fit_x(self.weights, self.biases, self.activation,
+                                  np.atleast_2d(np.asarray(X_obs, dtype=np.float64)), Y_obs, hyp["alpha"], hyp["beta"],
+                                  hyp["mean"], want_nll=want_nll)
 
     def _is_resident(self, X1):
         return isinstance(X1, DeviceGrid) and X1.ctx is self.ctx and X1.shape[0] == self.ctx.grid_shape()[0] \

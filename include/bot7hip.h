@@ -172,6 +172,9 @@ int b7_blr_features(b7_ctx *ctx, const double *Z1, int64_t M, int z);
  * nll_out (nullable): negative log evidence, for sampling (alpha_prec, beta) on the host ('marginalize'). */
 int b7_blr_fit(b7_ctx *ctx, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta,
                double mean, double *nll_out);
+/* The same with Z0 = basis(X0) computed and kept on the device (models/dngo.lua:155-162 + :174 in one call). */
+int b7_blr_fit_x(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec,
+                 double beta, double mean, double *nll_out);
 /* mean = m0 + Z1 m, var = 1/beta + z' K^-1 z over the resident features; results stay on the device for the
  * b7_score_* calls (same accumulator and arg-max as the GP path). */
 int b7_blr_predict(b7_ctx *ctx, double *mean_host, double *var_host);

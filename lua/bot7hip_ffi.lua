@@ -38,6 +38,7 @@ typedef struct { int n_layers; const int *dims; const double *const *W; const do
 int  b7_blr_basis(b7_ctx *ctx, const b7_mlp *net, const double *X, int64_t M, double *Z_host);
 int  b7_blr_features(b7_ctx *ctx, const double *Z1, int64_t M, int z);
 int  b7_blr_fit(b7_ctx *ctx, const double *Z0, const double *Y0, int N, int z, double alpha_prec, double beta, double mean, double *nll_out);
+int  b7_blr_fit_x(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec, double beta, double mean, double *nll_out);
 int  b7_blr_predict(b7_ctx *ctx, double *mean_host, double *var_host);
 int  b7_score_reset(b7_ctx *ctx);
 int  b7_score_ei(b7_ctx *ctx, const double *fmin, double tradeoff);

@@ -1,5 +1,5 @@
 --[[
-Drop-in for bot7.models.dngo's predict path (models/dngo.lua:108-175) backed by b7_blr_basis / b7_blr_fit /
+Drop-in for bot7.models.dngo's predict path (models/dngo.lua:108-175) backed by b7_blr_fit_x / b7_blr_basis /
 b7_blr_predict.  The network is still built and trained by nnTools exactly as in the reference (:49-106,
 :126-152): this class only takes the trained nn.Linear layers up to the basis layer out of `self.network`,
 hands them to the GPU as plain arrays, and replaces the minibatch forward loops (:155-171) and the
@@ -45,10 +45,9 @@ function dngo:predict(X0, Y0, X1, hyp, req, skip)
   self.network:evaluate()
   local net, keep = pack_network(self)
   local z  = keep[3][#keep[1]]
-  local Z0 = torch.DoubleTensor(X0:size(1), z)
-  hip.check(hip.C.b7_blr_basis(hip.ctx, net, hip.ptr(X0), X0:size(1), torch.data(Z0)))          -- :155-162
   local h  = self.blr_hyp or {alpha = 1.0, beta = 1.0 / (1e-2 * Y0:var()), mean = Y0:mean()}
-  hip.check(hip.C.b7_blr_fit(hip.ctx, torch.data(Z0), hip.ptr(Y0), X0:size(1), z, h.alpha, h.beta, h.mean, nil))
+  -- :155-162 (features of X0) and the fit half of :174 in one call; Z0 never leaves the device
+  hip.check(hip.C.b7_blr_fit_x(hip.ctx, net, hip.ptr(X0), hip.ptr(Y0), X0:size(1), h.alpha, h.beta, h.mean, nil))
   local X = X1:contiguous()
   hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(X), X:size(1), X:size(2)))
   hip.grid_version = hip.grid_version + 1

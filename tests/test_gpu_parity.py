@@ -543,6 +543,8 @@ def test_dngo_basis_and_blr_head_match_oracle(ctx, orc):
         f = blr.fit(Z0_o, Y, alpha_p, beta, mean)
         nll = ctx.blr_fit(Z0, Y, alpha_p, beta, mean, want_nll=True)
         assert nll == pytest.approx(float(f["nll"]), rel=1e-9, abs=1e-7)
+        nll_x = ctx.blr_fit_x(W, b, act, X_obs, Y, alpha_p, beta, mean, want_nll=True)   # basis + fit on the device
+        assert nll_x == pytest.approx(float(f["nll"]), rel=1e-9, abs=1e-7)
         ctx.grid_upload(X_hid)
         Z1 = ctx.blr_basis(W, b, act, download=True)       # features of the resident grid, kept on the device
         assert np.allclose(Z1, blr.basis(X_hid, W, b, act), rtol=1e-12, atol=1e-13)
