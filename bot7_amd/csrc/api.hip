@@ -100,6 +100,7 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   if (const char *pv = getenv("B7_POST_VARIANT")) c->post_variant = atoi(pv);
   if (const char *pv = getenv("B7_KSX_ABLATE")) c->ksx_ablate = atoi(pv);
+  if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
     const int g = atoi(pv);
     if (g >= 1 && g <= 8) c->potrf_group = g;
@@ -576,12 +577,13 @@ int b7_gp_append(b7_ctx *c, const double *x_new, const double *y_new) {
   double *ls_dev = (double *)c->scratch.p;  // lengthscales of the current fit
   B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N + 1, d));
   // k = K(x_new, [X; x_new]) through the covariance kernel (row 0 of a 64-row launch)
-  B7_TRY(b7_ensure(c, c->fant, sizeof(double) * ((size_t)64 * np + 3 * (size_t)np + (size_t)np * 16 + 64)));
-  double *krows = (double *)c->fant.p, *lvec = krows + (size_t)64 * np, *uvec = lvec + np, *part = uvec + np;
+  B7_TRY(b7_ensure(c, c->fant, sizeof(double) * ((size_t)64 * np + 4 * (size_t)np + (size_t)np * 16 + 64)));
+  double *krows = (double *)c->fant.p, *lvec = krows + (size_t)64 * np, *uvec = lvec + np, *evec = uvec + np;
+  double *part = evec + np;
   int *status_dev = (int *)(part + (size_t)np * 16);
   B7_TRY(launch_ksx(c, (const double *)c->xobs.p + (size_t)N * d, 0, 64, 1, d, krows, nullptr, 1));
-  B7_TRY(launch_append_vectors(c, krows, lvec, uvec, part));
-  B7_TRY(launch_append_finalize(c, krows, lvec, uvec, status_dev));
+  B7_TRY(launch_append_vectors(c, krows, lvec, uvec, part, evec));
+  B7_TRY(launch_append_finalize(c, krows, lvec, uvec, evec, status_dev));
   int status = 0;
   B7_HIP(c, hipMemcpyAsync(&status, status_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   B7_HIP(c, hipStreamSynchronize(c->stream));

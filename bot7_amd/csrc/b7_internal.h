@@ -72,6 +72,7 @@ struct b7_ctx {
   bool acc_valid = false;
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
+  int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
   int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
@@ -162,8 +163,9 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
 int launch_fantasy_sample(b7_ctx *c, const double *Lp, const double *mu, int P, int n, uint64_t seed, double *out);
 int launch_add_diag(b7_ctx *c, double *S, int ld, int n, double v);
 
-int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, const double *uvec, int *status_dev);
-int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part);
+int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, const double *uvec, const double *evec,
+                           int *status_dev);
+int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part, double *evec);
 int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
                        int n_layers, int activation, double *out, int ld_out);
 int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,

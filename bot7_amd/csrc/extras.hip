@@ -258,22 +258,36 @@ __global__ void blr_assemble_kernel(const double *__restrict__ G, double *__rest
 // status[0] = 1 if lambda^2 is not positive (the caller then refits from scratch with the jitter schedule).
 __global__ void __launch_bounds__(256)
     append_finalize_kernel(const double *__restrict__ krow, const double *__restrict__ lvec,
-                           const double *__restrict__ uvec, double noise, int N, int Npad, double *__restrict__ K,
-                           double *__restrict__ L, double *__restrict__ Linv, int *__restrict__ status) {
-  __shared__ double red[256];
+                           const double *__restrict__ uvec, const double *__restrict__ evec, double noise, int N,
+                           int Npad, double *__restrict__ K, double *__restrict__ L, double *__restrict__ Linv,
+                           int *__restrict__ status) {
+  __shared__ double red[256], rede[256];
   __shared__ double lam_s;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < N; i += 256) s += lvec[i] * lvec[i];
+  double s = 0.0, se = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    s += lvec[i] * lvec[i];
+    se += fabs(lvec[i]) * evec[i];
+  }
   red[threadIdx.x] = s;
+  rede[threadIdx.x] = se;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      rede[threadIdx.x] += rede[threadIdx.x + o];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     const double kappa = krow[N] + noise;
     const double l2 = kappa - red[0];
-    if (!(l2 > 0.0)) {
+    // The new pivot l2 = kappa - |Linv k|^2 must stand clear of the rounding error of its own evaluation:
+    // |delta l_i| <= (N+2) u e_i with e = |Linv||k|, so |delta l2| <= 2 (N+2) u sum |l_i| e_i + (N+2) u |l|^2.
+    // Below that the sign of l2 is noise (an exact duplicate of an observation with no noise term lands here)
+    // and the extension is refused, as for a non-positive pivot; the caller refits with the jitter schedule.
+    const double u = 1.1102230246251565e-16, g = (double)(N + 2) * u;
+    const double tol = 2.0 * g * rede[0] + g * red[0];
+    if (!(l2 > tol)) {
       status[0] = 1;
       lam_s = 0.0;
     } else {
@@ -300,8 +314,9 @@ __global__ void __launch_bounds__(256)
 
 }  // namespace
 
-int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, const double *uvec, int *status_dev) {
-  hipLaunchKernelGGL(append_finalize_kernel, dim3(1), dim3(256), 0, c->stream, krow, lvec, uvec, c->noise, c->N,
+int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, const double *uvec, const double *evec,
+                           int *status_dev) {
+  hipLaunchKernelGGL(append_finalize_kernel, dim3(1), dim3(256), 0, c->stream, krow, lvec, uvec, evec, c->noise, c->N,
                      c->Npad, (double *)c->K.p, (double *)c->L.p, (double *)c->Linv.p, status_dev);
   B7_HIP(c, hipGetLastError());
   return B7_OK;

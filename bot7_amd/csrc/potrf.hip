@@ -67,6 +67,23 @@ __device__ __forceinline__ double row_share(double v) {  // value of lane J of t
   hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+// 64-bit row broadcast as ONE instruction (v_mov_b64_dpp row_newbcast: the only DPP control the fp64 ALU has)
+template <int J>
+__device__ __forceinline__ double row_share64(double v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, false);
+}
+// acc += (value of `src` in lane J of this lane's 16-lane row) * mul, as ONE instruction: v_fmac_f64 with its first
+// operand taken through DPP (5 cycles of issue; mov_dpp + fma is 8 + 5, the old 32-bit pair 16 + 5 --
+// tools/valu_probe.hip).  hipcc does not form it from mov_dpp + fma, hence the asm.  A DPP read needs two wait
+// states after a VALU write of the same register and the compiler cannot see into asm: the statements are volatile
+// (kept in program order) and every caller keeps at least two other instructions between the write of `src` and
+// this read (see the 16x16 routine; s_nop 1 would cost 8 cycles each).
+template <int J>
+__device__ __forceinline__ void fmac_share(double &acc, double src, double mul) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(mul), "n"(J));
+}
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -76,8 +93,13 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+template <int VAR, bool STAMP = false>
 __global__ void __launch_bounds__(256)
-    potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info) {
+    potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info,
+                      unsigned long long *__restrict__ stamps = nullptr) {
+#define B7_DIAG_STAMP(i) \
+  if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
+  B7_DIAG_STAMP(0);
   extern __shared__ __align__(16) double dsm[];
   double *A = dsm;                  // [64][DLD] working copy of the block, becomes L11
   double *X = dsm + NB * DLD;       // [64][DLD] inverse of L11 (zero above the diagonal)
@@ -85,16 +107,81 @@ __global__ void __launch_bounds__(256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   double *blk = L + ((int64_t)p * NB) * ld + (int64_t)p * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    int i = e >> 6, j = e & 63;
-    A[i * DLD + j] = blk[(int64_t)i * ld + j];
-    X[i * DLD + j] = 0.0;
+  {  // all eight 16-byte loads of a thread in flight at once (a load -> wait -> LDS store loop is 16 round trips)
+    double2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      v[t] = *reinterpret_cast<const double2 *>(blk + (int64_t)i * ld + j2);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      *reinterpret_cast<double2 *>(A + i * DLD + j2) = v[t];
+      *reinterpret_cast<double2 *>(X + i * DLD + j2) = make_double2(0.0, 0.0);
+    }
   }
   __syncthreads();
+  B7_DIAG_STAMP(1);
 
   for (int kb = 0; kb < 4; ++kb) {
     const int o = kb * 16;
-    if (wave == 0) {
+    if (VAR == 1 && wave == 0) {
+      // Square-root-free pivot chain, built for ISSUE cycles: one wave issues a VALU instruction every ~5 cycles
+      // and this routine is bound by that, not by latency (tools/valu_probe.hip).  Lane lr keeps row lr of
+      // C = L diag(sqrt(d)) (c_ij = l_ij sqrt(d_j), pivots d_j = c_jj).  Per column j: broadcast d_j, r_j = 1/d_j
+      // (estimate + 2 Newton steps), one multiplier -c_ij r_j, then one fused DPP multiply-add per remaining column.
+      // Row j of the UNIT-lower inverse (of C diag(r)) needs only r, so it rides along in the same block of
+      // straight-line code; the 16 values y_j = 1/sqrt(d_j) that turn C and that inverse into L and inv(L) are
+      // computed once, lane j doing y_j from the pivot it captured, and broadcast.  No branch inside the chain:
+      // a non-positive (or NaN) pivot is found afterwards from the captured pivots; the arithmetic after it is
+      // garbage that the host discards together with this attempt.
+      double a[16], x[16], xs[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = A[(o + lr) * DLD + o + k];
+      double dmine = 1.0;
+      static_for<16>([&](auto Jc) {
+        constexpr int j = Jc;
+        const double dj = row_share64<j>(a[j]);
+        dmine = (lr == j) ? dj : dmine;
+        double r = __builtin_amdgcn_rcp(dj);
+        r = __builtin_fma(__builtin_fma(-dj, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-dj, r, 1.0), r, r);
+        const double nm = -(a[j] * r);  // -l~_ij of the LDL' form (rows i > j)
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k > j) fmac_share<k>(a[k], a[j], nm);  // c_ik -= l~_ij c_kj; a[j] was last written >= 2 asm ago
+        });
+        // row j of the unit-lower inverse, lane lr holding column lr: x~_j = [j == lr] - sum_{k<j} c_jk (r_k x~_k)
+        double sacc = 0.0;
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k < j) fmac_share<j>(sacc, a[k], xs[k]);
+        });
+        x[j] = (j == lr) ? 1.0 : -sacc;  // lanes lr > j: every term was zero
+        xs[j] = x[j] * r;
+      });
+      const unsigned long long badmask = __ballot(!(dmine > 0.0)) & 0xFFFFull;  // also NaN, like dpotrf's test
+      if (badmask != 0 && lane == 0 && info[0] == 0) info[0] = p * NB + o + __ffsll((long long)badmask);
+      double ymine = __builtin_amdgcn_rsq(dmine);  // 1/sqrt(d_lr): hardware estimate + two Newton steps
+      const double hp = 0.5 * dmine;
+      ymine = ymine * __builtin_fma(-hp * ymine, ymine, 1.5);
+      ymine = ymine * __builtin_fma(-hp * ymine, ymine, 1.5);
+      static_for<16>([&](auto Kc) {
+        constexpr int k = Kc;
+        const double yk = row_share64<k>(ymine);
+        a[k] *= yk;  // L[lr][k] = c_lr,k / sqrt(d_k)
+        x[k] *= yk;  // inv(L)[k][lr] = x~_k / sqrt(d_k)
+      });
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
+          X[(o + k) * DLD + o + lr] = x[k];
+        }
+      }
+    }
+    if (VAR == 0 && wave == 0) {
       // every 16-lane row of the wave holds the same 16x16 sub-block (lane lr = matrix row lr)
       double a[16], r[16], x[16];
 #pragma unroll
@@ -141,7 +228,9 @@ __global__ void __launch_bounds__(256)
         }
       }
     }
+    B7_DIAG_STAMP(2 + 4 * kb);
     __syncthreads();
+    B7_DIAG_STAMP(3 + 4 * kb);
     // sub-panel: L_ik = A_ik * inv(L_kk)'  for block rows ib > kb, one 16x16 block per wave
     {
       const int ib = kb + 1 + wave;
@@ -155,6 +244,7 @@ __global__ void __launch_bounds__(256)
       }
     }
     __syncthreads();
+    B7_DIAG_STAMP(4 + 4 * kb);
     // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4
     {
       int pidx = 0;
@@ -172,6 +262,7 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
+    B7_DIAG_STAMP(5 + 4 * kb);
   }
 
   // doubling level 16 -> 32: pairs (0,1) and (2,3), one per wave; X_10 = -inv(L_11) * (L_10 * inv(L_00))
@@ -210,12 +301,15 @@ __global__ void __launch_bounds__(256)
     for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = xx[rr];
   }
   __syncthreads();
+  B7_DIAG_STAMP(18);
   double *dv = dinv + (int64_t)p * NB * NB;
   for (int e = tid; e < NB * NB; e += 256) {
     int i = e >> 6, j = e & 63;
     blk[(int64_t)i * ld + j] = (j <= i) ? A[i * DLD + j] : 0.0;
     dv[e] = X[i * DLD + j];
   }
+  B7_DIAG_STAMP(19);
+#undef B7_DIAG_STAMP
 }
 constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
 
@@ -339,6 +433,21 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// e = |Linv| * |r|: the magnitude sum behind each entry of Linv * r, i.e. (up to the unit roundoff and a term count)
+// the rounding-error bound of that entry.  b7_gp_append uses it to decide whether the new pivot is distinguishable
+// from zero at working precision.
+__global__ void __launch_bounds__(256)
+    trmv_lower_abs_kernel(const double *__restrict__ Linv, const double *__restrict__ r, double *__restrict__ e,
+                          int n, int nrows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double s = 0.0;
+  if (row < nrows)
+    for (int k = lane; k <= row; k += 64) s += fabs(Linv[(int64_t)row * n + k]) * fabs(r[k]);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) e[row] = s;
+}
+
 // alpha = Linv' * t in two passes with a fixed summation order: partial[ib][col] over 256-row slices, then their
 // sum in ascending ib.  Block = 64 columns x one 256-row slice (4 waves x 64 rows).
 constexpr int TSL = 256;
@@ -377,10 +486,11 @@ __global__ void __launch_bounds__(256)
 
 // The 64x64 factor-and-invert kernel on a stand-alone 64x64 matrix (fantasize's pending-point covariance).
 int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev) {
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel),
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, S, NB, 0, dinv_tmp, info_dev);
+  hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, S, NB, 0, dinv_tmp,
+                     info_dev);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -393,13 +503,41 @@ int launch_potrf(b7_ctx *c, double extra) {
   hipLaunchKernelGGL(copy_lower_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                      (const double *)c->K.p, L, n, c->N, extra);
   B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel),
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   // panels in pairs (a, b = a + 1): the narrow update of block column b after panel a, then ONE trailing update
   // with both panels (K = 128) for everything to the right of b.
   auto diag = [&](int p) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                       (double *)c->dinv.p, (int *)c->info.p);
+    if (p == 0 && c->W.p && getenv("B7_DIAG_STAMPS")) {  // diagnostic: phase times inside the first diagonal block
+      unsigned long long *st = (unsigned long long *)c->W.p, h[20];
+      if (c->diag_variant == 0)
+        hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                           (double *)c->dinv.p, (int *)c->info.p, st);
+      else
+        hipLaunchKernelGGL((potrf_diag_kernel<1, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                           (double *)c->dinv.p, (int *)c->info.p, st);
+      (void)hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      fprintf(stderr, "diag stamps (variant %d): load %llu |", c->diag_variant, h[1] - h[0]);
+      for (int kb = 0; kb < 4; ++kb)
+        fprintf(stderr, " kb%d: factor %llu sync %llu subpanel %llu update %llu |", kb,
+                h[2 + 4 * kb] - (kb ? h[1 + 4 * kb] : h[1]), h[3 + 4 * kb] - h[2 + 4 * kb],
+                h[4 + 4 * kb] - h[3 + 4 * kb], h[5 + 4 * kb] - h[4 + 4 * kb]);
+      fprintf(stderr, " doubling %llu store %llu total %llu\n", h[18] - h[17], h[19] - h[18], h[19] - h[0]);
+      return;
+    }
+    if (c->diag_variant == 0)
+      hipLaunchKernelGGL(potrf_diag_kernel<0>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p);
+    else
+      hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p);
   };
   auto trsm = [&](int p) {
     if (nb - p - 1 > 0)
@@ -479,10 +617,12 @@ __global__ void zero_tail_kernel(double *__restrict__ v, int from, int n) {
   const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = 0.0;
 }
-int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part) {
+int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part, double *evec) {
   const int n = c->Npad, nrows = c->N;
   hipLaunchKernelGGL(trmv_lower_kernel, dim3(n / 4), dim3(256), 0, c->stream, (const double *)c->Linv.p, krow, lvec, n,
                      1);
+  hipLaunchKernelGGL(trmv_lower_abs_kernel, dim3(n / 4), dim3(256), 0, c->stream, (const double *)c->Linv.p, krow,
+                     evec, n, nrows);
   hipLaunchKernelGGL(zero_tail_kernel, dim3((n - nrows + 255) / 256), dim3(256), 0, c->stream, lvec, nrows, n);
   const int nslices = (n + TSL - 1) / TSL;
   hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices), dim3(256), 0, c->stream,

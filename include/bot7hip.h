@@ -141,7 +141,9 @@ int b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, ui
 /* Incremental refit (bots/abstract.lua:137-144 appends one observation per trial): extends the CURRENT fit by one
  * observation (x_new[d], y_new[ycols]) under the same hypers in O(N^2): l = L^-1 k, lambda^2 = kappa - l'l, new rows
  * of L and L^-1, alpha recomputed.  Returns B7_ERR_STATE when the padded factor is full (N a multiple of 128) or
- * lambda^2 <= 0 -- refit with b7_gp_fit then (which also applies the jitter schedule). */
+ * lambda^2 does not stand clear of the rounding-error bound of its own evaluation,
+ * lambda^2 <= (N+2) u (2 |l|'(|L^-1||k|) + l'l), u = 2^-53 (this includes lambda^2 <= 0) -- refit with b7_gp_fit then
+ * (which also applies the jitter schedule). */
 int b7_gp_append(b7_ctx *ctx, const double *x_new, const double *y_new);
 
 /* Inspection (tests): lower Cholesky factor N x N, alpha N x ycols, explicit inverse factor N x N. */
