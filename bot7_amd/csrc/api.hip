@@ -101,6 +101,7 @@ int b7_create(b7_ctx **out, int device_id) {
   if (const char *pv = getenv("B7_POST_VARIANT")) c->post_variant = atoi(pv);
   if (const char *pv = getenv("B7_KSX_ABLATE")) c->ksx_ablate = atoi(pv);
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv) ? 1 : 0;
+  if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
     const int g = atoi(pv);
     if (g >= 1 && g <= 8) c->potrf_group = g;
@@ -281,8 +282,8 @@ int b7_gp_set_opts(b7_ctx *c, const b7_gp_opts *o) {
 }
 
 // One factorisation attempt of K + extra*I; returns dpotrf-style info through *info.
-static int try_factor(b7_ctx *c, double extra, int *info);
-static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out);
+static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse);
+static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse);
 
 int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,
               double *nll_out, double *jitter_used, int *info_out) {
@@ -334,7 +335,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
 
   int info_first = 0;
   double jitter = 0.0;
-  B7_TRY(chol_with_jitter(c, &jitter, &info_first));
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first, true));
   B7_TRY(launch_trtri(c));
   B7_TRY(launch_alpha(c));
   B7_HIP(c, hipStreamSynchronize(c->stream));
@@ -361,8 +362,8 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
 
 }  // extern "C"
 
-static int try_factor(b7_ctx *c, double extra, int *info) {
-  B7_TRY(launch_potrf(c, extra));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
+static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse) {
+  B7_TRY(launch_potrf(c, extra, with_inverse));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
   B7_HIP(c, hipMemcpyAsync(info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
@@ -370,11 +371,11 @@ static int try_factor(b7_ctx *c, double extra, int *info) {
 
 // utils/math.lua:159-218 on c->K (N x N inside Npad x Npad): plain attempt, then the growing-jitter retries on
 // the ORIGINAL matrix; leaves L and dinv on the device.
-static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out) {
+static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse) {
   const int N = c->N;
   const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   int info = 0;
-  B7_TRY(try_factor(c, 0.0, &info));
+  B7_TRY(try_factor(c, 0.0, &info, with_inverse));
   *info_first_out = info;
   double jitter = 0.0;
   if (info != 0) {
@@ -398,10 +399,11 @@ static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out) 
         for (size_t b = 0; b < np / B7_PANEL; ++b)
           for (int i = 0; i < B7_PANEL; ++i) di[b * B7_PANEL * B7_PANEL + i * B7_PANEL + i] = 1.0;
         B7_HIP(c, hipMemcpy(c->dinv.p, di.data(), sizeof(double) * np * B7_PANEL, hipMemcpyHostToDevice));
+        c->linv_done = false;  // launch_trtri rebuilds inv(L) from this L and dinv
         break;
       }
       eps = eps * c->opts.jitter_growth;  // :188
-      B7_TRY(try_factor(c, eps, &info));
+      B7_TRY(try_factor(c, eps, &info, with_inverse));
       if (info == 0) {
         jitter = eps;
         break;
@@ -455,7 +457,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
   B7_HIP(c, hipMemcpy(c->K.p, Kp.data(), nn, hipMemcpyHostToDevice));
   int info_first = 0;
   double jitter = 0.0;
-  B7_TRY(chol_with_jitter(c, &jitter, &info_first));
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first, false));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   B7_HIP(c, hipMemcpy2D(res, sizeof(double) * n, c->L.p, sizeof(double) * np, sizeof(double) * n, n,
                         hipMemcpyDeviceToHost));
@@ -727,7 +729,7 @@ static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_
                           (double *)c->resid.p));
   int info_first = 0;
   double jitter = 0.0;
-  B7_TRY(chol_with_jitter(c, &jitter, &info_first));
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first, true));
   B7_TRY(launch_trtri(c));
   B7_TRY(launch_alpha(c));
   B7_HIP(c, hipStreamSynchronize(c->stream));

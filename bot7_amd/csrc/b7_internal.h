@@ -73,6 +73,8 @@ struct b7_ctx {
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
+  int inverse_inline = 1;  // build inv(L) inside the factorisation launches (B7_INVERSE_INLINE=0: separate trtri passes)
+  bool linv_done = false;  // launch_potrf produced Linv for the current factor
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
   int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
@@ -147,8 +149,8 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
                double *mu, int ycols);
 
 // potrf.hip
-int launch_potrf(b7_ctx *c, double extra);  // K + extra*I -> L (writes c->L, c->dinv, c->info)
-int launch_trtri(b7_ctx *c);           // L, dinv -> Linv
+int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I -> L, dinv, info (+ Linv, using W)
+int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 
 // posterior.hip

@@ -93,14 +93,42 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// Workgroups 1.. of the launch (present when the inverse is being built alongside, see launch_potrf) do not touch
+// the diagonal block at all: they compute the K-chunk partial products of row block p of inv(L),
+//   W[c][:, tile j] = L[p, kc] * Linv[kc, tile j],   kc = [128 c, 128 c + 128) clipped to [64 j, 64 p),
+// which depend only on panels < p and therefore run on otherwise idle CUs while workgroup 0 is busy with the
+// serial factorisation.  potrf_trsm_kernel's extra workgroups finish the row: Linv[p, j] = -inv(L_pp) sum_c W[c].
 template <int VAR, bool STAMP = false>
 __global__ void __launch_bounds__(256)
     potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info,
-                      unsigned long long *__restrict__ stamps = nullptr) {
+                      unsigned long long *__restrict__ stamps, const double *__restrict__ Linv,
+                      double *__restrict__ Wpart) {
 #define B7_DIAG_STAMP(i) \
   if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
   B7_DIAG_STAMP(0);
   extern __shared__ __align__(16) double dsm[];
+  if (blockIdx.x > 0) {
+    int rem = blockIdx.x - 1, cch = 0;
+    const int PC = (p + 1) / 2;
+    for (; cch < PC; ++cch) {
+      const int cnt = (2 * cch + 2 < p) ? 2 * cch + 2 : p;  // tiles j whose K range [64 j, 64 p) meets chunk cch
+      if (rem < cnt) break;
+      rem -= cnt;
+    }
+    const int j = rem;
+    const int k0 = (128 * cch > NB * j) ? 128 * cch : NB * j;
+    const int k1 = (128 * cch + 128 < NB * p) ? 128 * cch + 128 : NB * p;
+    d4_t acc[2][2] = {};
+    G64NN::run(L + ((int64_t)p * NB) * ld, ld, Linv + (int64_t)j * NB, ld, k0, k1, acc, dsm);
+    double *out = Wpart + ((int64_t)cch * NB) * ld + (int64_t)j * NB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(int64_t)G64NN::out_row(i, r) * ld + G64NN::out_col(jj)] = acc[i][jj][r];
+    return;
+  }
   double *A = dsm;                  // [64][DLD] working copy of the block, becomes L11
   double *X = dsm + NB * DLD;       // [64][DLD] inverse of L11 (zero above the diagonal)
   double *T = X + NB * DLD;         // [32][TLD] scratch of the last doubling level
@@ -312,11 +340,96 @@ __global__ void __launch_bounds__(256)
 #undef B7_DIAG_STAMP
 }
 constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
+// With the inverse's partial products riding along, the launch asks for more than half a CU's LDS so that no
+// second workgroup lands on the CU that runs the factorisation: that code is bound by VALU issue slots and a
+// co-resident workgroup's waves would take them.
+constexpr int DIAG_LDS_EXCL_BYTES = 84 * 1024;
+static_assert(DIAG_LDS_EXCL_BYTES >= DIAG_LDS_BYTES, "exclusive size must cover the working set");
 
-// L21 tile <- A21 tile * inv(L11)'   (in place; the tile is fully read before it is written).
+// L21 tile <- A21 tile * inv(L11)'   (in place; the tile is fully read before it is written): workgroups [0, ntrsm).
+// Workgroups ntrsm + 4 j + slab, j in [0, nbt) (present when the inverse is built alongside) write tile j of row
+// block p of inv(L), a 16-column slab each:  j > p zero, j == p inv(L_pp), j < p  -inv(L_pp) * (sum over the K chunks of the partial products that
+// potrf_diag_kernel's extra workgroups left in W, added in ascending chunk order: a fixed summation order).
 __global__ void __launch_bounds__(256)
-    potrf_trsm_kernel(double *__restrict__ L, int ld, int p, const double *__restrict__ dinv) {
+    potrf_trsm_kernel(double *__restrict__ L, int ld, int p, const double *__restrict__ dinv, int ntrsm, int nbt,
+                      double *__restrict__ Linv, const double *__restrict__ Wpart) {
   __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
+  static_assert(2 * G64NT::STAGE_DOUBLES >= 2 * NB * DLD, "the inverse-row path reuses the GEMM staging area");
+  if ((int)blockIdx.x >= ntrsm) {
+    // one workgroup per 64 x 16 column slab of a tile: 2 x 16-byte loads per thread and chunk, so the partials of
+    // 16 chunks are in flight at once and the whole sum costs one memory round trip (a launch this short cannot
+    // afford one round trip per few chunks)
+    const int xb = blockIdx.x - ntrsm, j = xb >> 2, slab = xb & 3, tid = threadIdx.x;
+    double *out = Linv + ((int64_t)p * NB) * ld + (int64_t)j * NB + slab * 16;
+    const double *dv = dinv + (int64_t)p * NB * NB;
+    const int ri = tid >> 3, rc = (tid & 7) * 2;  // this thread's two double2 of a slab: rows ri and ri + 32
+    if (j >= p) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        double2 v = make_double2(0.0, 0.0);
+        if (j == p) v = *reinterpret_cast<const double2 *>(dv + (ri + 32 * h) * NB + slab * 16 + rc);
+        *reinterpret_cast<double2 *>(out + (int64_t)(ri + 32 * h) * ld + rc) = v;
+      }
+      return;
+    }
+    constexpr int SLD = 17;  // odd stride: the B-operand reads (k = lane >> 4, n = lane & 15) stay conflict-free
+    double *Dn = sm, *Ts = sm + NB * DLD;
+    const int PC = (p + 1) / 2;
+    {
+      double2 dn[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+        dn[t] = *reinterpret_cast<const double2 *>(dv + i * NB + j2);
+      }
+      double2 acc[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+      const double *src0 = Wpart + (int64_t)j * NB + slab * 16 + rc;
+      for (int c0 = j / 2; c0 < PC; c0 += 16) {
+        double2 v[16][2];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            v[u][h] = (c0 + u < PC) ? *reinterpret_cast<const double2 *>(
+                                          src0 + ((int64_t)(c0 + u) * NB + ri + 32 * h) * ld)
+                                    : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)  // ascending chunk order
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            acc[h].x += v[u][h].x;
+            acc[h].y += v[u][h].y;
+          }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        Ts[(ri + 32 * h) * SLD + rc] = acc[h].x;
+        Ts[(ri + 32 * h) * SLD + rc + 1] = acc[h].y;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+        *reinterpret_cast<double2 *>(Dn + i * DLD + j2) = dn[t];
+      }
+    }
+    __syncthreads();
+    // out[i][n] = -sum_{k <= i} Dn[i][k] Ts[k][n]: wave w owns rows 16w .. 16w+15; two accumulators alternate
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
+    d4_t c0a = {0.0, 0.0, 0.0, 0.0}, c1a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      if (kq > wave) break;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4 += 2) {
+        c0a = mfma_f64(-Dn[(wave * 16 + lr) * DLD + kq * 16 + 4 * s4 + lq], Ts[(kq * 16 + 4 * s4 + lq) * SLD + lr], c0a);
+        c1a = mfma_f64(-Dn[(wave * 16 + lr) * DLD + kq * 16 + 4 * s4 + 4 + lq],
+                       Ts[(kq * 16 + 4 * s4 + 4 + lq) * SLD + lr], c1a);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) out[(int64_t)(wave * 16 + lq + 4 * rr) * ld + lr] = c0a[rr] + c1a[rr];
+    return;
+  }
   double *tile = L + ((int64_t)(p + 1 + blockIdx.x) * NB) * ld + (int64_t)p * NB;
   d4_t acc[2][2] = {};
   G64NT::run(tile, ld, dinv + (int64_t)p * NB * NB, NB, 0, NB, acc, sm);
@@ -490,23 +603,31 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, S, NB, 0, dinv_tmp,
-                     info_dev);
+                     info_dev, (unsigned long long *)nullptr, (const double *)nullptr, (double *)nullptr);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
 
-int launch_potrf(b7_ctx *c, double extra) {
+// with_inverse: inv(L) is built row block by row block inside the factorisation's own launches (extra workgroups
+// of the diagonal-block and panel-solve kernels, see there), so it costs no launches and almost no time of its
+// own -- the factorisation is a chain of small dependent kernels that leaves most CUs idle.  Needs c->Linv and
+// c->W (n x n each).  Without it (b7_chol) only L and dinv are produced and launch_trtri is the way to inv(L).
+int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
   PhaseScope ps(c, "potrf");
   const int n = c->Npad, nb = n / NB;
   double *L = (double *)c->L.p;
+  with_inverse = with_inverse && c->inverse_inline;
+  c->linv_done = false;
+  const double *Linv = with_inverse ? (const double *)c->Linv.p : nullptr;
+  double *Wp = with_inverse ? (double *)c->W.p : nullptr;
   int64_t total = (int64_t)n * n;
   hipLaunchKernelGGL(copy_lower_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                      (const double *)c->K.p, L, n, c->N, extra);
   B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_EXCL_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_EXCL_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
@@ -514,14 +635,18 @@ int launch_potrf(b7_ctx *c, double extra) {
   // panels in pairs (a, b = a + 1): the narrow update of block column b after panel a, then ONE trailing update
   // with both panels (K = 128) for everything to the right of b.
   auto diag = [&](int p) {
+    // extra workgroups: the partial products of row block p of inv(L), sum over chunks c of min(p, 2c + 2) tiles
+    int nt = 0;
+    if (with_inverse)
+      for (int cc = 0; cc < (p + 1) / 2; ++cc) nt += (2 * cc + 2 < p) ? 2 * cc + 2 : p;
     if (p == 0 && c->W.p && getenv("B7_DIAG_STAMPS")) {  // diagnostic: phase times inside the first diagonal block
       unsigned long long *st = (unsigned long long *)c->W.p, h[20];
       if (c->diag_variant == 0)
         hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                           (double *)c->dinv.p, (int *)c->info.p, st);
+                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp);
       else
         hipLaunchKernelGGL((potrf_diag_kernel<1, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                           (double *)c->dinv.p, (int *)c->info.p, st);
+                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp);
       (void)hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream);
       (void)hipStreamSynchronize(c->stream);
       fprintf(stderr, "diag stamps (variant %d): load %llu |", c->diag_variant, h[1] - h[0]);
@@ -532,17 +657,19 @@ int launch_potrf(b7_ctx *c, double extra) {
       fprintf(stderr, " doubling %llu store %llu total %llu\n", h[18] - h[17], h[19] - h[18], h[19] - h[0]);
       return;
     }
+    const int lds = nt > 0 ? DIAG_LDS_EXCL_BYTES : DIAG_LDS_BYTES;
     if (c->diag_variant == 0)
-      hipLaunchKernelGGL(potrf_diag_kernel<0>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                         (double *)c->dinv.p, (int *)c->info.p);
+      hipLaunchKernelGGL(potrf_diag_kernel<0>, dim3(1 + nt), dim3(256), lds, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp);
     else
-      hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                         (double *)c->dinv.p, (int *)c->info.p);
+      hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1 + nt), dim3(256), lds, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp);
   };
   auto trsm = [&](int p) {
-    if (nb - p - 1 > 0)
-      hipLaunchKernelGGL(potrf_trsm_kernel, dim3(nb - p - 1), dim3(256), 0, c->stream, L, n, p,
-                         (const double *)c->dinv.p);
+    const int ntrsm = nb - p - 1, nx = with_inverse ? 4 * nb : 0;  // 4 column slabs per tile of the inverse row
+    if (ntrsm + nx > 0)
+      hipLaunchKernelGGL(potrf_trsm_kernel, dim3(ntrsm + nx), dim3(256), 0, c->stream, L, n, p,
+                         (const double *)c->dinv.p, ntrsm, nb, (double *)c->Linv.p, (const double *)Wp);
   };
   auto syrk = [&](int kc0, int kb, int j0, int ncols) {
     int tiles = 0;
@@ -590,10 +717,12 @@ int launch_potrf(b7_ctx *c, double extra) {
     if (next < nb) syrk(a, gsz, next, nb - next);  // everything right of the group, K = 64 * gsz
   }
   B7_HIP(c, hipGetLastError());
+  c->linv_done = with_inverse;
   return B7_OK;
 }
 
 int launch_trtri(b7_ctx *c) {
+  if (c->linv_done) return B7_OK;  // already built inside launch_potrf
   PhaseScope ps(c, "trtri");
   const int n = c->Npad;
   int64_t total = (int64_t)n * n;
