@@ -331,10 +331,22 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   B7_DIAG_STAMP(18);
   double *dv = dinv + (int64_t)p * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    int i = e >> 6, j = e & 63;
-    blk[(int64_t)i * ld + j] = (j <= i) ? A[i * DLD + j] : 0.0;
-    dv[e] = X[i * DLD + j];
+  {  // all LDS reads first, then 16-byte stores (same reason as the load above)
+    double2 va[8], vx[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      va[t] = *reinterpret_cast<const double2 *>(A + i * DLD + j2);
+      vx[t] = *reinterpret_cast<const double2 *>(X + i * DLD + j2);
+      if (j2 > i) va[t].x = 0.0;
+      if (j2 + 1 > i) va[t].y = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      *reinterpret_cast<double2 *>(blk + (int64_t)i * ld + j2) = va[t];
+      *reinterpret_cast<double2 *>(dv + i * NB + j2) = vx[t];
+    }
   }
   B7_DIAG_STAMP(19);
 #undef B7_DIAG_STAMP
