@@ -152,6 +152,7 @@ def test_argmax_semantics(ctx, orc):
 CASES = [  # (d, N, M, objective) -- ragged on purpose: N not a multiple of 64/128, M not a multiple of 128
     (2, 2, 7, B.braninhoo), (2, 24, 256, B.braninhoo), (6, 65, 1000, B.hartmann6), (6, 256, 4096, B.hartmann6),
     (32, 129, 515, B.ackley), (5, 300, 2049, B.rastrigin), (39, 64, 128, B.rastrigin),
+    (8, 2300, 600, B.rastrigin),   # 36 panels: more than 16 K-chunks per row block of the inline inverse
 ]
 
 
@@ -177,6 +178,26 @@ def test_fit_and_predict_match_oracle(ctx, orc, d, N, M, obj):
     mu2, var2 = ctx.gp_predict_at(X_hid[: min(M, 200)])
     assert np.array_equal(mu2, mu[: min(M, 200)]) and np.array_equal(var2, var[: min(M, 200)])
     assert ctx.grid_shape() == (M, d)
+
+
+def test_inline_inverse_matches_separate_pass(ctx, orc, monkeypatch):
+    """inv(L) built inside the Cholesky launches (default) against the stand-alone recursive-doubling pass."""
+    import bot7_amd
+    X_obs, Y, _, hyp = make_problem(ctx, orc, 6, 1100, 64, B.hartmann6)
+    monkeypatch.setenv("B7_INVERSE_INLINE", "0")
+    ref = bot7_amd.Context(0)
+    monkeypatch.delenv("B7_INVERSE_INLINE")
+    for c in (ctx, ref):
+        c.profile_enable(True)
+        c.profile_reset()
+        c.gp_fit(X_obs, Y, **hyp)
+    assert ctx.profile_get("trtri")[1] == 0 and ref.profile_get("trtri")[1] == 1     # (ms, count): the pass is gone
+    (L0, a0, Li0), (L1, a1, Li1) = ctx.gp_download(1100), ref.gp_download(1100)
+    assert np.array_equal(L0, L1)
+    assert np.allclose(Li0, Li1, rtol=0, atol=1e-11 * np.abs(Li1).max())
+    assert np.array_equal(np.triu(Li0, 1), np.zeros_like(Li0))
+    assert relerr(a0, a1, floor=1e-3 * np.abs(a1).max()) < 1e-9
+    ref.close() if hasattr(ref, "close") else None
 
 
 def test_golden_gp_fixture(ctx, orc):
