@@ -73,7 +73,8 @@ struct b7_ctx {
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
-  int inverse_inline = 1;  // build inv(L) inside the factorisation launches (B7_INVERSE_INLINE=0: separate trtri passes)
+  int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
+                           // Npad <= 4096, 2 always (B7_INVERSE_INLINE)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
