@@ -74,8 +74,9 @@ struct b7_ctx {
   size_t ks_bytes = (size_t)4 << 30;
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
   int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
-                           // Npad <= 4096, 2 always (B7_INVERSE_INLINE)
+                           // Npad <= 8192, 2 always (B7_INVERSE_INLINE)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
+  int potrf_defer = 1;   // far part of each trailing update rides on the next diagonal-block launch (B7_POTRF_DEFER)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
   int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them

@@ -37,6 +37,42 @@ constexpr int NB = B7_PANEL;  // 64
 using G64NT = GemmF64<64, 64, 32, 2, 2, false>;
 using G64NN = GemmF64<64, 64, 32, 2, 2, true>;
 
+// One 64x64 tile of a trailing update: A[I][J] -= L[I][kc0 .. kc0+kb) L[J][kc0 .. kc0+kb)', (I, J) the rem-th lower
+// tile of block columns [j0, j0 + ncols) counted column by column.  The C tile is fetched before the product so
+// its latency hides under the MFMAs.  sm: 2 * G64NT::STAGE_DOUBLES doubles of LDS.
+template <bool STAMP>
+__device__ __forceinline__ void syrk_tile(double *__restrict__ L, int ld, int kc0, int kb, int j0, int ncols, int nbt,
+                                          int rem, double *__restrict__ sm, unsigned long long *__restrict__ stamps) {
+  int J = j0;
+  for (int c = 0; c < ncols; ++c, ++J) {
+    const int h = nbt - J;
+    if (rem < h) break;
+    rem -= h;
+  }
+  const int I = J + rem;
+  const double *a = L + ((int64_t)I * NB) * ld + (int64_t)kc0 * NB;
+  const double *b = L + ((int64_t)J * NB) * ld + (int64_t)kc0 * NB;
+  double *cblk = L + ((int64_t)I * NB) * ld + (int64_t)J * NB;
+  d4_t cin[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cin[i][j][r] = cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)];
+  d4_t acc[2][2] = {};
+  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+  G64NT::run(a, ld, b, ld, 0, kb * NB, acc, sm);
+  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = cin[i][j][r] - acc[i][j][r];
+}
+
 // L <- block-lower part of K (upper 64x64 blocks zeroed).
 // `extra` (the jitter of this attempt) is added to the first nreal diagonal entries: src + eps*I.
 __global__ void __launch_bounds__(256)
@@ -98,15 +134,21 @@ __device__ __forceinline__ void static_for(F &&f) {
 //   W[c][:, tile j] = L[p, kc] * Linv[kc, tile j],   kc = [128 c, 128 c + 128) clipped to [64 j, 64 p),
 // which depend only on panels < p and therefore run on otherwise idle CUs while workgroup 0 is busy with the
 // serial factorisation.  potrf_trsm_kernel's extra workgroups finish the row: Linv[p, j] = -inv(L_pp) sum_c W[c].
+// Workgroups nt + 1.. are tiles of the previous panel group's trailing update that nothing needs before the NEXT
+// group (block columns beyond this group's own): deferred to here for the same reason.
 template <int VAR, bool STAMP = false>
 __global__ void __launch_bounds__(256)
     potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info,
                       unsigned long long *__restrict__ stamps, const double *__restrict__ Linv,
-                      double *__restrict__ Wpart) {
+                      double *__restrict__ Wpart, int nt, int s_kc0, int s_kb, int s_j0, int s_ncols, int nbt) {
 #define B7_DIAG_STAMP(i) \
   if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
   B7_DIAG_STAMP(0);
   extern __shared__ __align__(16) double dsm[];
+  if ((int)blockIdx.x > nt) {  // a deferred trailing-update tile of the previous panel group (see launch_potrf)
+    syrk_tile<false>(L, ld, s_kc0, s_kb, s_j0, s_ncols, nbt, (int)blockIdx.x - 1 - nt, dsm, nullptr);
+    return;
+  }
   if (blockIdx.x > 0) {
     int rem = blockIdx.x - 1, cch = 0;
     const int PC = (p + 1) / 2;
@@ -352,11 +394,9 @@ __global__ void __launch_bounds__(256)
 #undef B7_DIAG_STAMP
 }
 constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
-// With the inverse's partial products riding along, the launch asks for more than half a CU's LDS so that no
-// second workgroup lands on the CU that runs the factorisation: that code is bound by VALU issue slots and a
-// co-resident workgroup's waves would take them.
-constexpr int DIAG_LDS_EXCL_BYTES = 84 * 1024;
-static_assert(DIAG_LDS_EXCL_BYTES >= DIAG_LDS_BYTES, "exclusive size must cover the working set");
+// Riding workgroups (inverse partial products, deferred trailing-update tiles) may share the factorising CU: two
+// workgroups of this size fit, and keeping that CU exclusive (a larger LDS request) measured 2 % slower at
+// N = 2048 because the riders then need a second round of CUs.
 
 // L21 tile <- A21 tile * inv(L11)'   (in place; the tile is fully read before it is written): workgroups [0, ntrsm).
 // Workgroups ntrsm + 4 j + slab, j in [0, nbt) (present when the inverse is built alongside) write tile j of row
@@ -462,35 +502,8 @@ __global__ void __launch_bounds__(256, 2)
     potrf_syrk_kernel(double *__restrict__ L, int ld, int kc0, int kb, int j0, int ncols, int nbt,
                       unsigned long long *__restrict__ stamps) {
   if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
-  int J = j0, rem = blockIdx.x;
-  for (int c = 0; c < ncols; ++c, ++J) {
-    const int h = nbt - J;
-    if (rem < h) break;
-    rem -= h;
-  }
-  const int I = J + rem;
   __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
-  const double *a = L + ((int64_t)I * NB) * ld + (int64_t)kc0 * NB;
-  const double *b = L + ((int64_t)J * NB) * ld + (int64_t)kc0 * NB;
-  double *cblk = L + ((int64_t)I * NB) * ld + (int64_t)J * NB;
-  d4_t cin[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cin[i][j][r] = cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)];
-  d4_t acc[2][2] = {};
-  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-  G64NT::run(a, ld, b, ld, 0, kb * NB, acc, sm);
-  if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = cin[i][j][r] - acc[i][j][r];
+  syrk_tile<STAMP>(L, ld, kc0, kb, j0, ncols, nbt, blockIdx.x, sm, stamps);
   if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
@@ -615,7 +628,8 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, S, NB, 0, dinv_tmp,
-                     info_dev, (unsigned long long *)nullptr, (const double *)nullptr, (double *)nullptr);
+                     info_dev, (unsigned long long *)nullptr, (const double *)nullptr, (double *)nullptr, 0, 0, 0, 0, 0,
+                     1);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -628,10 +642,9 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
   PhaseScope ps(c, "potrf");
   const int n = c->Npad, nb = n / NB;
   double *L = (double *)c->L.p;
-  // The riding workgroups run one per CU (the launch is sized to keep the factorising CU to itself), so once a row
-  // block has many more partial products than there are CUs the stand-alone GEMM passes are the better way:
-  // measured inline vs separate 0.89 / 1.10 ms at N = 2048, 2.6 / 3.0 at 4096, 13.9 / 12.5 at 8192.
-  with_inverse = with_inverse && c->inverse_inline && (n <= 4096 || c->inverse_inline > 1);
+  // Once a row block has many more partial products than the CUs can take next to the factorisation the gain
+  // fades: measured inline vs separate passes 0.84 / 1.05 ms at N = 2048, 2.5 / 2.9 at 4096, 12.2 / 12.4 at 8192.
+  with_inverse = with_inverse && c->inverse_inline && (n <= 8192 || c->inverse_inline > 1);
   c->linv_done = false;
   const double *Linv = with_inverse ? (const double *)c->Linv.p : nullptr;
   double *Wp = with_inverse ? (double *)c->W.p : nullptr;
@@ -640,15 +653,17 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
                      (const double *)c->K.p, L, n, c->N, extra);
   B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_EXCL_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_EXCL_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   // panels in pairs (a, b = a + 1): the narrow update of block column b after panel a, then ONE trailing update
   // with both panels (K = 128) for everything to the right of b.
+  // deferred part of the previous group's trailing update: (kc0, kb, j0, ncols), taken by the next diag launch
+  struct Deferred { int kc0, kb, j0, ncols, tiles; } pend = {0, 0, 0, 0, 0};
   auto diag = [&](int p) {
     // extra workgroups: the partial products of row block p of inv(L), sum over chunks c of min(p, 2c + 2) tiles
     int nt = 0;
@@ -658,10 +673,10 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
       unsigned long long *st = (unsigned long long *)c->W.p, h[20];
       if (c->diag_variant == 0)
         hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp);
+                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp, 0, 0, 0, 0, 0, nb);
       else
         hipLaunchKernelGGL((potrf_diag_kernel<1, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp);
+                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp, 0, 0, 0, 0, 0, nb);
       (void)hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream);
       (void)hipStreamSynchronize(c->stream);
       fprintf(stderr, "diag stamps (variant %d): load %llu |", c->diag_variant, h[1] - h[0]);
@@ -672,13 +687,16 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
       fprintf(stderr, " doubling %llu store %llu total %llu\n", h[18] - h[17], h[19] - h[18], h[19] - h[0]);
       return;
     }
-    const int lds = nt > 0 ? DIAG_LDS_EXCL_BYTES : DIAG_LDS_BYTES;
+    const int ns = pend.tiles;
     if (c->diag_variant == 0)
-      hipLaunchKernelGGL(potrf_diag_kernel<0>, dim3(1 + nt), dim3(256), lds, c->stream, L, n, p,
-                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp);
+      hipLaunchKernelGGL(potrf_diag_kernel<0>, dim3(1 + nt + ns), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp, nt,
+                         pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
     else
-      hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1 + nt), dim3(256), lds, c->stream, L, n, p,
-                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp);
+      hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1 + nt + ns), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp, nt,
+                         pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
+    pend.tiles = 0;
   };
   auto trsm = [&](int p) {
     const int ntrsm = nb - p - 1, nx = with_inverse ? 4 * nb : 0;  // 4 column slabs per tile of the inverse row
@@ -728,8 +746,20 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
       diag(p);
       trsm(p);
     }
+    // The group's trailing update, K = 64 * gsz, in two parts: the next group's own block columns now, everything
+    // beyond them as extra workgroups of the next group's first diagonal-block launch (nothing reads those tiles
+    // before that group's own trailing update, and that launch keeps one CU busy for 13 us).  Same products in the
+    // same order on every tile: bit-identical to the one-launch form (B7_POTRF_DEFER=0).
     const int next = a + gsz;
-    if (next < nb) syrk(a, gsz, next, nb - next);  // everything right of the group, K = 64 * gsz
+    if (next < nb) {
+      const int near = c->potrf_defer ? ((nb - next < G) ? nb - next : G) : nb - next;
+      syrk(a, gsz, next, near);
+      const int far0 = next + near;
+      if (far0 < nb) {
+        pend = {a, gsz, far0, nb - far0, 0};
+        for (int J = far0; J < nb; ++J) pend.tiles += nb - J;
+      }
+    }
   }
   B7_HIP(c, hipGetLastError());
   c->linv_done = with_inverse;
