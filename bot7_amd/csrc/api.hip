@@ -102,6 +102,8 @@ int b7_create(b7_ctx **out, int device_id) {
   if (const char *pv = getenv("B7_KSX_ABLATE")) c->ksx_ablate = atoi(pv);
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
+  if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv) ? 1 : 0;
+  if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
     const int g = atoi(pv);

@@ -76,6 +76,9 @@ struct b7_ctx {
   int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
                            // Npad <= 8192, 2 always (B7_INVERSE_INLINE)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
+  int potrf_sched = 1;   // 1: one panel at a time, near update fused into the panel solve, far update riding on the
+                         // next diagonal-block launch; 0: panel groups with separate update launches (B7_POTRF_SCHED)
+  int syrk_small = 1;    // whole-K single-stage kernel for trailing updates with <= 256 tiles (B7_SYRK_SMALL)
   int potrf_defer = 1;   // far part of each trailing update rides on the next diagonal-block launch (B7_POTRF_DEFER)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274

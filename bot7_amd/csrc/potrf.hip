@@ -36,11 +36,17 @@ constexpr int NB = B7_PANEL;  // 64
 // of fixed cost (barrier + restage) next to 1024 cycles of MFMA per 16 of depth, so fewer, deeper stages win.
 using G64NT = GemmF64<64, 64, 32, 2, 2, false>;
 using G64NN = GemmF64<64, 64, 32, 2, 2, true>;
+// Whole-K single-stage forms for the launches ON the critical path that have fewer tiles than CUs (panel solve,
+// narrow update, the near part of the trailing update): one workgroup per CU has nothing to overlap a staged K loop
+// with, so every stage's load latency is exposed (a K = 128 update cost >= 8.2 us however few its tiles); with all of
+// K in LDS at once there is ONE load round trip and the MFMAs issue back to back.  Same k order: bit-identical.
+using G64NT_K64 = GemmF64<64, 64, 64, 2, 2, false>;
+using G64NT_K128 = GemmF64<64, 64, 128, 2, 2, false>;
 
 // One 64x64 tile of a trailing update: A[I][J] -= L[I][kc0 .. kc0+kb) L[J][kc0 .. kc0+kb)', (I, J) the rem-th lower
 // tile of block columns [j0, j0 + ncols) counted column by column.  The C tile is fetched before the product so
 // its latency hides under the MFMAs.  sm: 2 * G64NT::STAGE_DOUBLES doubles of LDS.
-template <bool STAMP>
+template <bool STAMP, class G = G64NT>
 __device__ __forceinline__ void syrk_tile(double *__restrict__ L, int ld, int kc0, int kb, int j0, int ncols, int nbt,
                                           int rem, double *__restrict__ sm, unsigned long long *__restrict__ stamps) {
   int J = j0;
@@ -59,10 +65,10 @@ __device__ __forceinline__ void syrk_tile(double *__restrict__ L, int ld, int kc
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cin[i][j][r] = cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)];
+      for (int r = 0; r < 4; ++r) cin[i][j][r] = cblk[(int64_t)G::out_row(i, r) * ld + G::out_col(j)];
   d4_t acc[2][2] = {};
   if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-  G64NT::run(a, ld, b, ld, 0, kb * NB, acc, sm);
+  G::run(a, ld, b, ld, 0, kb * NB, acc, sm);
   if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -70,7 +76,7 @@ __device__ __forceinline__ void syrk_tile(double *__restrict__ L, int ld, int kc
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        cblk[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = cin[i][j][r] - acc[i][j][r];
+        cblk[(int64_t)G::out_row(i, r) * ld + G::out_col(j)] = cin[i][j][r] - acc[i][j][r];
 }
 
 // L <- block-lower part of K (upper 64x64 blocks zeroed).
@@ -402,10 +408,17 @@ constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
 // Workgroups ntrsm + 4 j + slab, j in [0, nbt) (present when the inverse is built alongside) write tile j of row
 // block p of inv(L), a 16-column slab each:  j > p zero, j == p inv(L_pp), j < p  -inv(L_pp) * (sum over the K chunks of the partial products that
 // potrf_diag_kernel's extra workgroups left in W, added in ascending chunk order: a fixed summation order).
+// NEAR (the one-panel-at-a-time schedule, see launch_potrf): workgroup b < ntrsm also applies panel p's update to
+// its tile of the NEXT block column, A[I][p+1] -= L[I][p] L[p+1][p]', which is all the next diagonal block and the
+// next panel solve need; it forms L[p+1][p] itself from the inverse it has staged anyway (redundant across the
+// workgroups, but a launch of its own would cost more than the 40 MFMAs per wave).
+constexpr int TRSM_LDS_BYTES = 2 * G64NT::STAGE_DOUBLES * 8;
+constexpr int NEAR_LDS_BYTES = 3 * NB * DLD * 8;
+template <bool NEAR>
 __global__ void __launch_bounds__(256)
     potrf_trsm_kernel(double *__restrict__ L, int ld, int p, const double *__restrict__ dinv, int ntrsm, int nbt,
                       double *__restrict__ Linv, const double *__restrict__ Wpart) {
-  __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
+  extern __shared__ __align__(16) double sm[];
   static_assert(2 * G64NT::STAGE_DOUBLES >= 2 * NB * DLD, "the inverse-row path reuses the GEMM staging area");
   if ((int)blockIdx.x >= ntrsm) {
     // one workgroup per 64 x 16 column slab of a tile: 2 x 16-byte loads per thread and chunk, so the partials of
@@ -482,15 +495,89 @@ __global__ void __launch_bounds__(256)
     for (int rr = 0; rr < 4; ++rr) out[(int64_t)(wave * 16 + lq + 4 * rr) * ld + lr] = c0a[rr] + c1a[rr];
     return;
   }
+  static_assert(2 * G64NT::STAGE_DOUBLES >= G64NT_K64::STAGE_DOUBLES, "one whole-K stage fits the staging area");
   double *tile = L + ((int64_t)(p + 1 + blockIdx.x) * NB) * ld + (int64_t)p * NB;
+  if (NEAR) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    double *Ai = sm, *Aq = sm + NB * DLD, *Xp = sm + 2 * NB * DLD;
+    const double *tq = L + ((int64_t)(p + 1) * NB) * ld + (int64_t)p * NB;  // A[p+1][p]
+    const double *dv = dinv + (int64_t)p * NB * NB;
+    double *ctile = tile + NB;  // A[I][p+1]
+    {
+      double2 va[8], vq[8], vx[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+        va[t] = *reinterpret_cast<const double2 *>(tile + (int64_t)i * ld + j2);
+        vq[t] = *reinterpret_cast<const double2 *>(tq + (int64_t)i * ld + j2);
+        vx[t] = *reinterpret_cast<const double2 *>(dv + i * NB + j2);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+        *reinterpret_cast<double2 *>(Ai + i * DLD + j2) = va[t];
+        *reinterpret_cast<double2 *>(Aq + i * DLD + j2) = vq[t];
+        *reinterpret_cast<double2 *>(Xp + i * DLD + j2) = vx[t];
+      }
+    }
+    d4_t cin[4];  // this wave's 16 rows of the C tile, in accumulator layout; in flight under the two solves
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) cin[jb][rr] = ctile[(int64_t)(wave * 16 + lq + 4 * rr) * ld + jb * 16 + lr];
+    __syncthreads();
+    // both solves: out[a][j] = sum_{k <= j} A[a][k] X[j][k]   (X lower triangular: whole 16-blocks above skipped)
+    d4_t li[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    d4_t lqv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ko = kq * 16 + 4 * s4 + lq;
+        const double ai = Ai[(wave * 16 + lr) * DLD + ko], aq = Aq[(wave * 16 + lr) * DLD + ko];
+#pragma unroll
+        for (int jb = kq; jb < 4; ++jb) {
+          const double xb = Xp[(jb * 16 + lr) * DLD + ko];
+          li[jb] = mfma_f64(ai, xb, li[jb]);
+          lqv[jb] = mfma_f64(aq, xb, lqv[jb]);
+        }
+      }
+    __syncthreads();  // every wave is done reading Ai / Aq
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 16 + lq + 4 * rr, col = jb * 16 + lr;
+        Ai[row * DLD + col] = li[jb][rr];
+        Aq[row * DLD + col] = lqv[jb][rr];
+        tile[(int64_t)row * ld + col] = li[jb][rr];  // L[I][p]
+      }
+    __syncthreads();
+    d4_t u[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ko = kq * 16 + 4 * s4 + lq;
+        const double ai = Ai[(wave * 16 + lr) * DLD + ko];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) u[jb] = mfma_f64(ai, Aq[(jb * 16 + lr) * DLD + ko], u[jb]);
+      }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        ctile[(int64_t)(wave * 16 + lq + 4 * rr) * ld + jb * 16 + lr] = cin[jb][rr] - u[jb][rr];
+    return;
+  }
   d4_t acc[2][2] = {};
-  G64NT::run(tile, ld, dinv + (int64_t)p * NB * NB, NB, 0, NB, acc, sm);
+  G64NT_K64::run(tile, ld, dinv + (int64_t)p * NB * NB, NB, 0, NB, acc, sm);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tile[(int64_t)G64NT::out_row(i, r) * ld + G64NT::out_col(j)] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) tile[(int64_t)G64NT_K64::out_row(i, r) * ld + G64NT_K64::out_col(j)] = acc[i][j][r];
 }
 
 // Trailing update: A[I][J] -= L[I][kc0 .. kc0+kb) L[J][kc0 .. kc0+kb)'   for block columns J in [j0, j0+ncols) and
@@ -505,6 +592,15 @@ __global__ void __launch_bounds__(256, 2)
   __shared__ __align__(16) double sm[2 * G64NT::STAGE_DOUBLES];
   syrk_tile<STAMP>(L, ld, kc0, kb, j0, ncols, nbt, blockIdx.x, sm, stamps);
   if (STAMP && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+}
+
+// The same update for launches with fewer tiles than CUs: all of K = 64 KB staged at once (dynamic LDS).
+template <int KB>
+__global__ void __launch_bounds__(256)
+    potrf_syrk_small_kernel(double *__restrict__ L, int ld, int kc0, int j0, int ncols, int nbt) {
+  extern __shared__ __align__(16) double dsm_small[];
+  using G = typename std::conditional<KB == 1, G64NT_K64, G64NT_K128>::type;
+  syrk_tile<false, G>(L, ld, kc0, KB, j0, ncols, nbt, blockIdx.x, dsm_small, nullptr);
 }
 
 // Linv <- blockdiag(dinv), zero elsewhere.
@@ -660,6 +756,10 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K64::STAGE_DOUBLES * 8));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K128::STAGE_DOUBLES * 8));
   // panels in pairs (a, b = a + 1): the narrow update of block column b after panel a, then ONE trailing update
   // with both panels (K = 128) for everything to the right of b.
   // deferred part of the previous group's trailing update: (kc0, kb, j0, ncols), taken by the next diag launch
@@ -698,10 +798,18 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
                          pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
     pend.tiles = 0;
   };
-  auto trsm = [&](int p) {
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trsm_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trsm_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, NEAR_LDS_BYTES));
+  auto trsm = [&](int p, bool near) {
     const int ntrsm = nb - p - 1, nx = with_inverse ? 4 * nb : 0;  // 4 column slabs per tile of the inverse row
-    if (ntrsm + nx > 0)
-      hipLaunchKernelGGL(potrf_trsm_kernel, dim3(ntrsm + nx), dim3(256), 0, c->stream, L, n, p,
+    if (ntrsm + nx <= 0) return;
+    if (near)
+      hipLaunchKernelGGL(potrf_trsm_kernel<true>, dim3(ntrsm + nx), dim3(256), NEAR_LDS_BYTES, c->stream, L, n, p,
+                         (const double *)c->dinv.p, ntrsm, nb, (double *)c->Linv.p, (const double *)Wp);
+    else
+      hipLaunchKernelGGL(potrf_trsm_kernel<false>, dim3(ntrsm + nx), dim3(256), TRSM_LDS_BYTES, c->stream, L, n, p,
                          (const double *)c->dinv.p, ntrsm, nb, (double *)c->Linv.p, (const double *)Wp);
   };
   auto syrk = [&](int kc0, int kb, int j0, int ncols) {
@@ -730,13 +838,39 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
               tiles, t1 - t0, lastStart - t0, s01 / tiles, s12 / tiles, s23 / tiles);
       return;
     }
-    hipLaunchKernelGGL(potrf_syrk_kernel<false>, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb,
-                       (unsigned long long *)nullptr);
+    if (tiles <= 256 && kb == 1 && c->syrk_small)
+      hipLaunchKernelGGL(potrf_syrk_small_kernel<1>, dim3(tiles), dim3(256), G64NT_K64::STAGE_DOUBLES * 8, c->stream, L,
+                         n, kc0, j0, ncols, nb);
+    else if (tiles <= 256 && kb == 2 && c->syrk_small)
+      hipLaunchKernelGGL(potrf_syrk_small_kernel<2>, dim3(tiles), dim3(256), G64NT_K128::STAGE_DOUBLES * 8, c->stream,
+                         L, n, kc0, j0, ncols, nb);
+    else
+      hipLaunchKernelGGL(potrf_syrk_kernel<false>, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb,
+                         (unsigned long long *)nullptr);
   };
   // Panels in groups of G: inside a group every new panel first receives the updates of the group's earlier
   // panels on its own block column only (narrow, K = 64 q); the bulk of the trailing matrix is updated ONCE per
   // group with K = 64 G.  Larger G raises the bulk updates' MFMA utilisation but makes the narrow updates deep
   // and serial: measured potrf at N = 2048 is 1.07 ms for G = 1 and 2, 1.12 for 4, 1.27 for 8 (tools/potrf_ab.py).
+  if (c->potrf_sched == 1) {
+    // One panel at a time, two launches each, the rest riding along:
+    //   diag(p)   + riders: partial products of inverse row p, and the FAR part of panel p-1's update (block columns
+    //               >= p+1 ... i.e. everything but the column its own near part already did), K = 64 per tile
+    //   near(p)   panel solve of every tile row below + panel p's update of block column p+1 only (+ inverse row p)
+    // The critical path is diag -> near -> diag ...; each tile still receives the panels' updates in ascending
+    // order, one panel (K = 64) at a time.
+    for (int p = 0; p < nb; ++p) {
+      diag(p);
+      trsm(p, true);
+      if (p + 2 < nb) {
+        pend = {p, 1, p + 2, nb - (p + 2), 0};
+        for (int J = p + 2; J < nb; ++J) pend.tiles += nb - J;
+      }
+    }
+    B7_HIP(c, hipGetLastError());
+    c->linv_done = with_inverse;
+    return B7_OK;
+  }
   const int G = c->potrf_group;
   for (int a = 0; a < nb; a += G) {
     const int gsz = (nb - a < G) ? nb - a : G;
@@ -744,7 +878,7 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
       const int p = a + q;
       if (q > 0) syrk(a, q, p, 1);  // block column p <- panels a .. p-1
       diag(p);
-      trsm(p);
+      trsm(p, false);
     }
     // The group's trailing update, K = 64 * gsz, in two parts: the next group's own block columns now, everything
     // beyond them as extra workgroups of the next group's first diagonal-block launch (nothing reads those tiles
