@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256)
       *reinterpret_cast<double2 *>(X + i * DLD + j2) = make_double2(0.0, 0.0);
     }
   }
+  if (VAR == 1 && tid < 256) T[(tid >> 4) * TLD + (tid & 15)] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;  // I_16
   __syncthreads();
   B7_DIAG_STAMP(1);
 
@@ -212,9 +213,21 @@ __global__ void __launch_bounds__(256)
       // computed once, lane j doing y_j from the pivot it captured, and broadcast.  No branch inside the chain:
       // a non-positive (or NaN) pivot is found afterwards from the captured pivots; the arithmetic after it is
       // garbage that the host discards together with this attempt.
-      double a[16], x[16], xs[16];
+      // The recurrence that inverts the block, s_j = rhs_j - sum_{k<j} c_jk (r_k s_k), is a forward substitution
+      // with the identity as right-hand side.  The four 16-lane rows of the wave replicate the factorisation
+      // anyway (DPP broadcasts stay inside a row), so rows 1..3 run the SAME instructions on a different right-hand
+      // side: one row each of the sub-panel blocks below, which come out solved (L_ik = A_ik inv(L_kk)') for free.
+      double a[16], x[16], xs[16], rhs[16];
+      const int ib = kb + lq;  // sub-panel block of this lane row (lq >= 1); lane row 0 carries the inverse
+      const bool has_sub = lq > 0 && ib < 4;
+      // every lane reads its right-hand side through one pointer, no selects: the identity rows live in T
+      // (written before the loop), lane rows without a block read zeros from X's upper triangle
+      const double *rsrc = (lq == 0) ? T + lr * TLD : (has_sub ? A + (ib * 16 + lr) * DLD + o : X + 48);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = A[(o + lr) * DLD + o + k];
+      for (int k = 0; k < 16; ++k) {
+        a[k] = A[(o + lr) * DLD + o + k];
+        rhs[k] = rsrc[k];
+      }
       double dmine = 1.0;
       static_for<16>([&](auto Jc) {
         constexpr int j = Jc;
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(256)
           constexpr int k = Kc;
           if constexpr (k < j) fmac_share<j>(sacc, a[k], xs[k]);
         });
-        x[j] = (j == lr) ? 1.0 : -sacc;  // lanes lr > j: every term was zero
+        x[j] = rhs[j] - sacc;
         xs[j] = x[j] * r;
       });
       const unsigned long long badmask = __ballot(!(dmine > 0.0)) & 0xFFFFull;  // also NaN, like dpotrf's test
@@ -247,14 +260,17 @@ __global__ void __launch_bounds__(256)
         constexpr int k = Kc;
         const double yk = row_share64<k>(ymine);
         a[k] *= yk;  // L[lr][k] = c_lr,k / sqrt(d_k)
-        x[k] *= yk;  // inv(L)[k][lr] = x~_k / sqrt(d_k)
+        x[k] *= yk;  // lane row 0: inv(L)[k][lr] = s_k / sqrt(d_k); lane rows 1..3: L_ik[lr][k]
       });
+      // one store loop for all lanes: lane row 0 writes its column of inv(L_kk) (stride DLD), rows 1..3 their
+      // solved sub-panel row (stride 1), rows without a block into T's spare columns (never read)
+      double *wdst = (lq == 0) ? X + o * DLD + o + lr : (has_sub ? A + (ib * 16 + lr) * DLD + o : T + lr * TLD + 16);
+      const int wstride = (lq == 0) ? DLD : 1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wdst[k * wstride] = x[k];
       if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
-          X[(o + k) * DLD + o + lr] = x[k];
-        }
+        for (int k = 0; k < 16; ++k) A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
       }
     }
     if (VAR == 0 && wave == 0) {
@@ -307,8 +323,8 @@ __global__ void __launch_bounds__(256)
     B7_DIAG_STAMP(2 + 4 * kb);
     __syncthreads();
     B7_DIAG_STAMP(3 + 4 * kb);
-    // sub-panel: L_ik = A_ik * inv(L_kk)'  for block rows ib > kb, one 16x16 block per wave
-    {
+    // sub-panel: L_ik = A_ik * inv(L_kk)'  for block rows ib > kb, one 16x16 block per wave (VAR 1 solved it above)
+    if (VAR == 0) {
       const int ib = kb + 1 + wave;
       if (ib < 4) {
         d4_t c = {0.0, 0.0, 0.0, 0.0};
@@ -318,8 +334,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) A[(ib * 16 + lq + 4 * rr) * DLD + o + lr] = c[rr];
       }
+      __syncthreads();
     }
-    __syncthreads();
     B7_DIAG_STAMP(4 + 4 * kb);
     // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4
     {
