@@ -9,14 +9,18 @@
 //                           scores/expected_improvement.lua:63); the op order inside the absent `gp`
 //                           package is unknown, tolerance-checked against oracle/gp.py
 //
-// Structure (all extents padded to multiples of 64/128 by the caller; padding = identity):
-//   per 64-wide panel p:  diag   one workgroup factors the 64x64 diagonal block in LDS and inverts it
-//                         trsm   L21 = A21 * inv(L11)'            (MFMA, one 64x64 tile per workgroup)
-//   per group of G = 2 panels:  syrk   narrow update of the next panel's block column inside the group (K = 64),
-//                         then ONE update A22 -= L21 L21' of everything right of the group with K = 64 G
-//                         (MFMA, 1-D grid over the lower tiles: the trailing update)
-//   inverse of L by recursive doubling over block size s = 64,128,...: for each pair [A 0; B C] of
-//   already-inverted diagonal blocks, X = -inv(C) * (B * inv(A)); two batched MFMA GEMMs per level.
+// Structure (all extents padded to multiples of 64/128 by the caller; padding = identity).  The factorisation is a
+// chain of small dependent launches (each costs >= 4 us however little it does), so the schedule keeps TWO launches
+// per 64-wide panel on the critical path and hangs everything else on them as extra workgroups ("riders"):
+//   diag(p)   workgroup 0 factors the 64x64 diagonal block in LDS and inverts it;
+//             riders: the far part of panel p-1's trailing update (block columns >= p+1), and the K-chunk partial
+//             products of row block p of inv(L)
+//   near(p)   one workgroup per tile row below: L21 = A21 * inv(L11)' and panel p's update of block column p+1
+//             only (all the next diag needs); riders: row block p of inv(L) = -inv(L_pp) * (sum of the partials)
+// (B7_POTRF_SCHED=0 selects the earlier schedule: panel pairs, separate narrow / K = 128 trailing-update launches.)
+// Without the inline inverse (b7_chol, or Npad > 8192) inv(L) comes from recursive doubling over block size
+// s = 64,128,...: for each pair [A 0; B C] of already-inverted diagonal blocks, X = -inv(C) * (B * inv(A)); two
+// batched MFMA GEMMs per level (launch_trtri).
 // The explicit inverse is what lets the posterior variance be one GEMM with a fused column sum of squares
 // (posterior.hip) instead of a triangular solve that would have to store L^-1 K*'.
 #include "b7_internal.h"
