@@ -200,6 +200,26 @@ def test_inline_inverse_matches_separate_pass(ctx, orc, monkeypatch):
     ref.close() if hasattr(ref, "close") else None
 
 
+@pytest.mark.parametrize("env", [{"B7_POTRF_SCHED": "0"}, {"B7_POTRF_SCHED": "0", "B7_POTRF_DEFER": "0"},
+                                 {"B7_POTRF_SCHED": "0", "B7_SYRK_SMALL": "0", "B7_POTRF_GROUP": "4"},
+                                 {"B7_DIAG_VARIANT": "0", "B7_POTRF_SCHED": "0", "B7_INVERSE_INLINE": "0"}])
+def test_cholesky_schedules_agree(ctx, orc, monkeypatch, env):
+    """The alternative Cholesky schedules / kernels kept behind environment switches give the same factor."""
+    import bot7_amd
+    X_obs, Y, _, hyp = make_problem(ctx, orc, 6, 700, 64, B.hartmann6)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = bot7_amd.Context(0)
+    for k in env:
+        monkeypatch.delenv(k)
+    ctx.gp_fit(X_obs, Y, **hyp)
+    alt.gp_fit(X_obs, Y, **hyp)
+    (L0, a0, Li0), (L1, a1, Li1) = ctx.gp_download(700), alt.gp_download(700)
+    assert np.allclose(L0, L1, rtol=0, atol=1e-12 * np.abs(L1).max())
+    assert np.allclose(Li0, Li1, rtol=0, atol=1e-10 * np.abs(Li1).max())
+    assert relerr(a0, a1, floor=1e-3 * np.abs(a1).max()) < 1e-6   # alpha = K^-1 r: ulp-level L differences x cond(K)
+
+
 def test_golden_gp_fixture(ctx, orc):
     g = np.load(os.path.join(GOLD, "gp_small.npz"))
     ctx.gp_fit(g["X_obs"], g["Y_obs"], g["lenscale_sq"], float(g["amp"]), float(g["noise"]), float(g["mean"]))
