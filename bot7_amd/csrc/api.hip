@@ -287,6 +287,9 @@ int b7_gp_set_opts(b7_ctx *c, const b7_gp_opts *o) {
 // One factorisation attempt of K + extra*I; returns dpotrf-style info through *info.
 static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse);
 static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse);
+static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse);
+// device result block of a fit: int info[4] | double nll_terms[1 + 256]
+static constexpr size_t B7_INFO_BYTES = 16 + sizeof(double) * 257;
 
 int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,
               double *nll_out, double *jitter_used, int *info_out) {
@@ -324,7 +327,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
   B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np * c->yld));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np * ycols));
-  B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
+  B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
 
   // uploads (stream-ordered; the pageable source is consumed before the call returns via the sync below)
   double *ls_dev = (double *)c->scratch.p;  // first 4096 bytes of scratch: up to 512 doubles
@@ -336,27 +339,36 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
   B7_TRY(launch_kxx(c, hyp->noise));
 
-  int info_first = 0;
-  double jitter = 0.0;
-  B7_TRY(chol_with_jitter(c, &jitter, &info_first, true));
-  B7_TRY(launch_trtri(c));
-  B7_TRY(launch_alpha(c));
-  B7_HIP(c, hipStreamSynchronize(c->stream));
-
-  if (nll_out) {
-    std::vector<double> diag(N), al((size_t)N * ycols);
-    B7_HIP(c, hipMemcpy2D(diag.data(), sizeof(double), c->L.p, sizeof(double) * (np + 1), sizeof(double), N,
-                          hipMemcpyDeviceToHost));
-    B7_HIP(c, hipMemcpy2D(al.data(), sizeof(double) * ycols, c->alpha.p, sizeof(double) * c->yld,
-                          sizeof(double) * ycols, N, hipMemcpyDeviceToHost));
-    double logdet = 0.0;
-    for (int i = 0; i < N; ++i) logdet += log(diag[i]);
-    for (int k = 0; k < ycols; ++k) {
-      double q = 0.0;
-      for (int i = 0; i < N; ++i) q += r[(size_t)i * ycols + k] * al[(size_t)i * ycols + k];
-      nll_out[k] = 0.5 * q + logdet + 0.5 * N * log(2.0 * M_PI);
-    }
+  // First attempt with everything that follows it enqueued BEFORE the host looks at the pivot report: when the
+  // inverse came out of the factorisation itself, alpha and the likelihood terms do not need the host, and one
+  // small copy (info + terms) with one synchronisation ends the fit.  A failed pivot (rare) falls back to the
+  // jitter schedule and redoes the tail.
+  struct { int info[4]; double terms[257]; } blk;
+  double *terms_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(c->info.p) + 16);
+  const size_t blk_bytes = 16 + sizeof(double) * (nll_out ? 1 + ycols : 0);
+  B7_TRY(launch_potrf(c, 0.0, true));
+  bool tail_done = c->linv_done;
+  if (tail_done) {
+    B7_TRY(launch_alpha(c));
+    if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
   }
+  B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, tail_done ? blk_bytes : 16, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  const int info_first = blk.info[0];
+  double jitter = 0.0;
+  if (info_first != 0) {
+    B7_TRY(jitter_retries(c, &jitter, true));
+    tail_done = false;
+  }
+  if (!tail_done) {
+    B7_TRY(launch_trtri(c));
+    B7_TRY(launch_alpha(c));
+    if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
+    B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, blk_bytes, hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  if (nll_out)
+    for (int k = 0; k < ycols; ++k) nll_out[k] = 0.5 * blk.terms[1 + k] + blk.terms[0] + 0.5 * N * log(2.0 * M_PI);
   if (jitter_used) *jitter_used = jitter;
   if (info_out) *info_out = info_first;
   c->fitted = true;
@@ -375,13 +387,21 @@ static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse) {
 // utils/math.lua:159-218 on c->K (N x N inside Npad x Npad): plain attempt, then the growing-jitter retries on
 // the ORIGINAL matrix; leaves L and dinv on the device.
 static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse) {
-  const int N = c->N;
-  const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   int info = 0;
   B7_TRY(try_factor(c, 0.0, &info, with_inverse));
   *info_first_out = info;
+  *jitter_out = 0.0;
+  if (info != 0) B7_TRY(jitter_retries(c, jitter_out, with_inverse));
+  return B7_OK;
+}
+
+// The retries of utils/math.lua:174-202 after a failed plain attempt.
+static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse) {
+  const int N = c->N;
+  const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
+  int info = 1;
   double jitter = 0.0;
-  if (info != 0) {
+  {
     // max_eps = src:norm() (Frobenius) of the N x N matrix that was handed to chol (:174)
     std::vector<double> Kh((size_t)N * N);
     B7_HIP(c, hipMemcpy2D(Kh.data(), sizeof(double) * N, c->K.p, sizeof(double) * np, sizeof(double) * N, N,
@@ -449,7 +469,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
   B7_TRY(b7_ensure(c, c->K, nn));
   B7_TRY(b7_ensure(c, c->L, nn));
   B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
-  B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
+  B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
   std::vector<double> Kp(np * np, 0.0);
   for (size_t i = 0; i < np; ++i) {
     if (i < (size_t)n)
@@ -720,7 +740,7 @@ static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_
   B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np));
   B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)nk));
-  B7_TRY(b7_ensure(c, c->info, 4 * sizeof(int)));
+  B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
   std::vector<double> rb((size_t)nk, 0.0);
   for (int i = 0; i < N; ++i) rb[i] = beta * (Y0[i] - mean);
   B7_HIP(c, hipMemcpyAsync(c->tmpvar.p, rb.data(), sizeof(double) * nk, hipMemcpyHostToDevice, c->stream));

@@ -157,6 +157,7 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
 int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I -> L, dinv, info (+ Linv, using W)
 int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
+int launch_nll_terms(b7_ctx *c, double *out_dev);  // out[0] = sum log L_ii, out[1 + k] = r_k' alpha_k
 
 // posterior.hip
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var);

@@ -961,6 +961,51 @@ int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *u
   return B7_OK;
 }
 
+// out[0] = sum_i log L_ii, out[1 + k] = r_k' alpha_k: the two reductions of the negative log marginal likelihood, so
+// that a fit hands the host (info, nll terms) in ONE small copy instead of a strided diagonal and alpha.
+namespace {
+__global__ void __launch_bounds__(256)
+    nll_terms_kernel(const double *__restrict__ L, const double *__restrict__ resid, const double *__restrict__ alpha,
+                     int N, int ld, int ycols, int yld, double *__restrict__ out) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int i = t; i < N; i += 256) s += log(L[(int64_t)i * (ld + 1)]);
+  red[t] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[0] = red[0];
+  if (ycols == 1) {
+    __syncthreads();
+    double q = 0.0;
+    for (int i = t; i < N; i += 256) q += resid[i] * alpha[(int64_t)i * yld];
+    red[t] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) red[t] += red[t + o];
+      __syncthreads();
+    }
+    if (t == 0) out[1] = red[0];
+  } else {
+    for (int k = t; k < ycols; k += 256) {  // one column per thread, rows in order
+      double q = 0.0;
+      for (int i = 0; i < N; ++i) q += resid[(int64_t)i * ycols + k] * alpha[(int64_t)i * yld + k];
+      out[1 + k] = q;
+    }
+  }
+}
+}  // namespace
+
+int launch_nll_terms(b7_ctx *c, double *out_dev) {
+  hipLaunchKernelGGL(nll_terms_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->L.p,
+                     (const double *)c->resid.p, (const double *)c->alpha.p, c->N, c->Npad, c->ycols, c->yld, out_dev);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
 int launch_alpha(b7_ctx *c) {
   PhaseScope ps(c, "alpha");
   const int n = c->Npad;
