@@ -100,7 +100,11 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   if (const char *pv = getenv("B7_POST_VARIANT")) c->post_variant = atoi(pv);
   if (const char *pv = getenv("B7_KSX_ABLATE")) c->ksx_ablate = atoi(pv);
+  // tuning / diagnostic switches: read once here, never in the launch paths
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv) ? 1 : 0;
+  c->diag_stamps = getenv("B7_DIAG_STAMPS") != nullptr;
+  c->syrk_stamps = getenv("B7_SYRK_STAMPS") != nullptr;
+  c->mlp_scalar = getenv("B7_MLP_SCALAR") != nullptr;
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;

@@ -76,6 +76,8 @@ struct b7_ctx {
   int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
                            // Npad <= 8192, 2 always (B7_INVERSE_INLINE)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
+  bool diag_stamps = false, syrk_stamps = false;  // diagnostics: s_memtime phase stamps (B7_DIAG_STAMPS, B7_SYRK_STAMPS)
+  bool mlp_scalar = false;                       // force the scalar basis-network kernel (B7_MLP_SCALAR)
   int potrf_sched = 1;   // 1: one panel at a time, near update fused into the panel solve, far update riding on the
                          // next diagonal-block launch; 0: panel groups with separate update launches (B7_POTRF_SCHED)
   int syrk_small = 1;    // whole-K single-stage kernel for trailing updates with <= 256 tiles (B7_SYRK_SMALL)

@@ -789,7 +789,7 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
     int nt = 0;
     if (with_inverse)
       for (int cc = 0; cc < (p + 1) / 2; ++cc) nt += (2 * cc + 2 < p) ? 2 * cc + 2 : p;
-    if (p == 0 && c->W.p && getenv("B7_DIAG_STAMPS")) {  // diagnostic: phase times inside the first diagonal block
+    if (p == 0 && c->W.p && c->diag_stamps) {  // diagnostic: phase times inside the first diagonal block
       unsigned long long *st = (unsigned long long *)c->W.p, h[20];
       if (c->diag_variant == 0)
         hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
@@ -836,7 +836,7 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
     int tiles = 0;
     for (int J = j0; J < j0 + ncols; ++J) tiles += nb - J;
     if (tiles <= 0) return;
-    if (getenv("B7_SYRK_STAMPS") && kb == c->potrf_group && kc0 == 0) {  // diagnostic: per-block phase times of the first big update
+    if (c->syrk_stamps && kb == c->potrf_group && kc0 == 0) {  // diagnostic: per-block phase times of the first big update
       unsigned long long *st = (unsigned long long *)c->W.p;  // W is allocated by gp_fit (not by b7_chol)
       hipLaunchKernelGGL(potrf_syrk_kernel<true>, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb, st);
       std::vector<unsigned long long> h((size_t)tiles * 4);

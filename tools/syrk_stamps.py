@@ -4,6 +4,8 @@ import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["B7_SYRK_STAMPS"] = "1"
+os.environ["B7_POTRF_SCHED"] = "0"   # the pair schedule with stand-alone K = 128 update launches
+os.environ["B7_POTRF_DEFER"] = "0"
 import bot7_amd  # noqa: E402
 from bot7_amd import benchmarks  # noqa: E402
 c = bot7_amd.Context(0)
