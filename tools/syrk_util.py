@@ -1,5 +1,6 @@
 """MFMA utilisation of the Cholesky trailing updates from a rocprofv3 kernel-trace of tools/fit_once.py.
-usage: syrk_util.py <trace-dir> <N>.  Launch order per pair of panels (group size 2): narrow (K = 64, one block
+usage: syrk_util.py <trace-dir> <N>; the trace must come from the pair schedule with stand-alone update launches
+(B7_POTRF_SCHED=0 B7_POTRF_DEFER=0 in the environment of fit_once.py).  Launch order per pair of panels (group size 2): narrow (K = 64, one block
 column), bulk (K = 128, everything right of the pair); tiles = workgroups; flop = tiles * 64*64*K*2."""
 import csv
 import glob
