@@ -106,7 +106,7 @@ int b7_create(b7_ctx **out, int device_id) {
   c->syrk_stamps = getenv("B7_SYRK_STAMPS") != nullptr;
   c->mlp_scalar = getenv("B7_MLP_SCALAR") != nullptr;
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
-  if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv) ? 1 : 0;
+  if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {

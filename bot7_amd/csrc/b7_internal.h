@@ -78,8 +78,9 @@ struct b7_ctx {
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
   bool diag_stamps = false, syrk_stamps = false;  // diagnostics: s_memtime phase stamps (B7_DIAG_STAMPS, B7_SYRK_STAMPS)
   bool mlp_scalar = false;                       // force the scalar basis-network kernel (B7_MLP_SCALAR)
-  int potrf_sched = 1;   // 1: one panel at a time, near update fused into the panel solve, far update riding on the
-                         // next diagonal-block launch; 0: panel groups with separate update launches (B7_POTRF_SCHED)
+  int potrf_sched = 1;   // 1: one panel at a time (near update fused into the panel solve, far update riding on the
+                         // next diagonal-block launch) for Npad <= 4096, 2: always; 0: panel groups with separate
+                         // update launches (B7_POTRF_SCHED)
   int syrk_small = 1;    // whole-K single-stage kernel for trailing updates with <= 256 tiles (B7_SYRK_SMALL)
   int potrf_defer = 1;   // far part of each trailing update rides on the next diagonal-block launch (B7_POTRF_DEFER)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at

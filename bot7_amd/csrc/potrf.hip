@@ -872,7 +872,9 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
   // panels on its own block column only (narrow, K = 64 q); the bulk of the trailing matrix is updated ONCE per
   // group with K = 64 G.  Larger G raises the bulk updates' MFMA utilisation but makes the narrow updates deep
   // and serial: measured potrf at N = 2048 is 1.07 ms for G = 1 and 2, 1.12 for 4, 1.27 for 8 (tools/potrf_ab.py).
-  if (c->potrf_sched == 1) {
+  // measured pair schedule vs this one: 0.386 / 0.347 ms at N = 1024, 0.83 / 0.76 at 2048, 2.48 / 2.33 at 4096,
+  // 12.2 / 12.6 at 8192 (K = 64 rider tiles by the thousand): one panel at a time up to Npad = 4096
+  if ((c->potrf_sched == 1 && n <= 4096) || c->potrf_sched == 2) {
     // One panel at a time, two launches each, the rest riding along:
     //   diag(p)   + riders: partial products of inverse row p, and the FAR part of panel p-1's update (block columns
     //               >= p+1 ... i.e. everything but the column its own near part already did), K = 64 per tile
