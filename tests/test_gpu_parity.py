@@ -153,6 +153,7 @@ CASES = [  # (d, N, M, objective) -- ragged on purpose: N not a multiple of 64/1
     (2, 2, 7, B.braninhoo), (2, 24, 256, B.braninhoo), (6, 65, 1000, B.hartmann6), (6, 256, 4096, B.hartmann6),
     (32, 129, 515, B.ackley), (5, 300, 2049, B.rastrigin), (39, 64, 128, B.rastrigin),
     (8, 2300, 600, B.rastrigin),   # 36 panels: more than 16 K-chunks per row block of the inline inverse
+    (4, 4200, 300, B.rastrigin),   # Npad > 4096: the pair schedule of the Cholesky takes over
 ]
 
 
