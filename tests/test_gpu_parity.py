@@ -181,6 +181,23 @@ def test_fit_and_predict_match_oracle(ctx, orc, d, N, M, obj):
     assert ctx.grid_shape() == (M, d)
 
 
+@pytest.mark.parametrize("N", [2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 513])
+def test_fit_at_panel_boundaries(ctx, orc, N):
+    """Every N around the 64-wide panel and 128-row padding boundaries: factor, inverse, alpha and a few predictions."""
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 3, N, 40, B.rastrigin)
+    f = orc.gp.fit(X_obs, Y, **hyp)
+    out = ctx.gp_fit(X_obs, Y, **hyp)
+    assert out["info"] == 0
+    L, alpha, Linv = ctx.gp_download(N)
+    assert np.allclose(L, f.L, rtol=1e-9, atol=1e-12 * np.sqrt(hyp["amp"]))
+    assert np.allclose(Linv @ f.L, np.eye(N), atol=1e-7)
+    assert relerr(alpha, f.alpha, floor=np.abs(f.alpha).max() * 1e-3) < 1e-6
+    ctx.grid_upload(X_hid)
+    mu, var = ctx.gp_predict()
+    mu_o, var_o = orc.gp.predict(f, X_hid)
+    assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+
+
 def test_inline_inverse_matches_separate_pass(ctx, orc, monkeypatch):
     """inv(L) built inside the Cholesky launches (default) against the stand-alone recursive-doubling pass."""
     import bot7_amd
