@@ -328,7 +328,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_TRY(b7_ensure(c, c->L, nn));
   B7_TRY(b7_ensure(c, c->Linv, nn));
   B7_TRY(b7_ensure(c, c->W, nn));
-  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * (np + B7_PANEL) * B7_PANEL));
   B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np * c->yld));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np * ycols));
   B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
@@ -472,7 +472,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
   const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->K, nn));
   B7_TRY(b7_ensure(c, c->L, nn));
-  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * (np + B7_PANEL) * B7_PANEL));
   B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
   std::vector<double> Kp(np * np, 0.0);
   for (size_t i = 0; i < np; ++i) {
@@ -740,7 +740,7 @@ static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_
   B7_TRY(b7_ensure(c, c->L, nn));
   B7_TRY(b7_ensure(c, c->Linv, nn));
   B7_TRY(b7_ensure(c, c->W, nn));
-  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * np * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * (np + B7_PANEL) * B7_PANEL));
   B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np));
   B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)nk));

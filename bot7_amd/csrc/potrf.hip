@@ -155,12 +155,33 @@ __global__ void __launch_bounds__(256)
   if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
   B7_DIAG_STAMP(0);
   extern __shared__ __align__(16) double dsm[];
-  if ((int)blockIdx.x > nt) {  // a deferred trailing-update tile of the previous panel group (see launch_potrf)
-    syrk_tile<false>(L, ld, s_kc0, s_kb, s_j0, s_ncols, nbt, (int)blockIdx.x - 1 - nt, dsm, nullptr);
+  // workgroup 1 (when there is a tile below): copy A[p+1][p] to the scratch tile behind dinv.  The near kernel's
+  // workgroups all read that tile while four of them overwrite it in place with L[p+1][p]; reading the copy made
+  // HERE, one launch earlier, takes the race away at no cost to the factorisation.
+  const int ncopy = (p + 1 < nbt && gridDim.x > 1) ? 1 : 0;
+  if (ncopy && blockIdx.x == 1) {
+    const double *below = L + ((int64_t)(p + 1) * NB) * ld + (int64_t)p * NB;
+    double *aq = dinv + (int64_t)nbt * NB * NB;
+    double2 w[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = threadIdx.x + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      w[t] = *reinterpret_cast<const double2 *>(below + (int64_t)i * ld + j2);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = threadIdx.x + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      *reinterpret_cast<double2 *>(aq + i * NB + j2) = w[t];
+    }
+    return;
+  }
+  const int rider = (int)blockIdx.x - 1 - ncopy;  // index among the riders proper
+  if (rider >= nt) {  // a deferred trailing-update tile of the previous panel group (see launch_potrf)
+    syrk_tile<false>(L, ld, s_kc0, s_kb, s_j0, s_ncols, nbt, rider - nt, dsm, nullptr);
     return;
   }
   if (blockIdx.x > 0) {
-    int rem = blockIdx.x - 1, cch = 0;
+    int rem = rider, cch = 0;
     const int PC = (p + 1) / 2;
     for (; cch < PC; ++cch) {
       const int cnt = (2 * cch + 2 < p) ? 2 * cch + 2 : p;  // tiles j whose K range [64 j, 64 p) meets chunk cch
@@ -433,7 +454,7 @@ constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
 // next panel solve need; it forms L[p+1][p] itself from the inverse it has staged anyway (redundant across the
 // workgroups, but a launch of its own would cost more than the 40 MFMAs per wave).
 constexpr int TRSM_LDS_BYTES = 2 * G64NT::STAGE_DOUBLES * 8;
-constexpr int NEAR_LDS_BYTES = 3 * NB * DLD * 8;
+constexpr int NEAR_LDS_BYTES = (16 + 2 * NB) * DLD * 8;  // a 16-row slab, A[p+1][p] and inv(L_pp); >= the inverse-row path's 2 tiles
 template <bool NEAR>
 __global__ void __launch_bounds__(256)
     potrf_trsm_kernel(double *__restrict__ L, int ld, int p, const double *__restrict__ dinv, int ntrsm, int nbt,
@@ -518,76 +539,66 @@ __global__ void __launch_bounds__(256)
   static_assert(2 * G64NT::STAGE_DOUBLES >= G64NT_K64::STAGE_DOUBLES, "one whole-K stage fits the staging area");
   double *tile = L + ((int64_t)(p + 1 + blockIdx.x) * NB) * ld + (int64_t)p * NB;
   if (NEAR) {
+    // One workgroup per 16-row slab of a tile (4 per tile): a tile's three products on ONE CU are 144 dependent-rate
+    // MFMAs per wave (3.8 us of a 9 us launch); as slabs it is 40 (L[p+1][p], still redundant) + <= 16 + 16, and a
+    // block column still has fewer workgroups than the chip has CUs.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    double *Ai = sm, *Aq = sm + NB * DLD, *Xp = sm + 2 * NB * DLD;
-    const double *tq = L + ((int64_t)(p + 1) * NB) * ld + (int64_t)p * NB;  // A[p+1][p]
+    const int slab = blockIdx.x & 3, r0 = slab * 16;
+    tile = L + ((int64_t)(p + 1 + (blockIdx.x >> 2)) * NB) * ld + (int64_t)p * NB;
+    double *Ai = sm, *Aq = sm + 16 * DLD, *Xp = sm + (16 + NB) * DLD;
+    const double *tq = dinv + (int64_t)nbt * NB * NB;  // A[p+1][p]: the copy the diag launch left behind dinv
     const double *dv = dinv + (int64_t)p * NB * NB;
     double *ctile = tile + NB;  // A[I][p+1]
     {
-      double2 va[8], vq[8], vx[8];
+      double2 va[2], vq[8], vx[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
-        va[t] = *reinterpret_cast<const double2 *>(tile + (int64_t)i * ld + j2);
-        vq[t] = *reinterpret_cast<const double2 *>(tq + (int64_t)i * ld + j2);
+        if (t < 2) va[t] = *reinterpret_cast<const double2 *>(tile + (int64_t)(r0 + i) * ld + j2);
+        vq[t] = *reinterpret_cast<const double2 *>(tq + i * NB + j2);
         vx[t] = *reinterpret_cast<const double2 *>(dv + i * NB + j2);
       }
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
-        *reinterpret_cast<double2 *>(Ai + i * DLD + j2) = va[t];
+        if (t < 2) *reinterpret_cast<double2 *>(Ai + i * DLD + j2) = va[t];
         *reinterpret_cast<double2 *>(Aq + i * DLD + j2) = vq[t];
         *reinterpret_cast<double2 *>(Xp + i * DLD + j2) = vx[t];
       }
     }
-    d4_t cin[4];  // this wave's 16 rows of the C tile, in accumulator layout; in flight under the two solves
+    d4_t cin;  // wave w owns column block w of the slab's C rows; in flight under the solves
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) cin[jb][rr] = ctile[(int64_t)(wave * 16 + lq + 4 * rr) * ld + jb * 16 + lr];
+    for (int rr = 0; rr < 4; ++rr) cin[rr] = ctile[(int64_t)(r0 + lq + 4 * rr) * ld + wave * 16 + lr];
     __syncthreads();
-    // both solves: out[a][j] = sum_{k <= j} A[a][k] X[j][k]   (X lower triangular: whole 16-blocks above skipped)
-    d4_t li[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    // solves: out[a][j] = sum_{k <= j} A[a][k] X[j][k]   (X lower triangular: whole 16-blocks above skipped).
+    // L[p+1][p]: wave w rows 16w.., all four column blocks.  The slab of L[I][p]: wave w column block w.
     d4_t lqv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    d4_t li = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int ko = kq * 16 + 4 * s4 + lq;
-        const double ai = Ai[(wave * 16 + lr) * DLD + ko], aq = Aq[(wave * 16 + lr) * DLD + ko];
+        const double aq = Aq[(wave * 16 + lr) * DLD + ko];
 #pragma unroll
-        for (int jb = kq; jb < 4; ++jb) {
-          const double xb = Xp[(jb * 16 + lr) * DLD + ko];
-          li[jb] = mfma_f64(ai, xb, li[jb]);
-          lqv[jb] = mfma_f64(aq, xb, lqv[jb]);
-        }
+        for (int jb = kq; jb < 4; ++jb) lqv[jb] = mfma_f64(aq, Xp[(jb * 16 + lr) * DLD + ko], lqv[jb]);
+        if (kq <= wave) li = mfma_f64(Ai[lr * DLD + ko], Xp[(wave * 16 + lr) * DLD + ko], li);
       }
     __syncthreads();  // every wave is done reading Ai / Aq
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int rr = 0; rr < 4; ++rr) {
+      Ai[(lq + 4 * rr) * DLD + wave * 16 + lr] = li[rr];
+      tile[(int64_t)(r0 + lq + 4 * rr) * ld + wave * 16 + lr] = li[rr];  // L[I][p]
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = wave * 16 + lq + 4 * rr, col = jb * 16 + lr;
-        Ai[row * DLD + col] = li[jb][rr];
-        Aq[row * DLD + col] = lqv[jb][rr];
-        tile[(int64_t)row * ld + col] = li[jb][rr];  // L[I][p]
-      }
+      for (int jb = 0; jb < 4; ++jb) Aq[(wave * 16 + lq + 4 * rr) * DLD + jb * 16 + lr] = lqv[jb][rr];
+    }
     __syncthreads();
-    d4_t u[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    d4_t u = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq)
+    for (int k4 = 0; k4 < 16; ++k4)
+      u = mfma_f64(Ai[lr * DLD + 4 * k4 + lq], Aq[(wave * 16 + lr) * DLD + 4 * k4 + lq], u);
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int ko = kq * 16 + 4 * s4 + lq;
-        const double ai = Ai[(wave * 16 + lr) * DLD + ko];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) u[jb] = mfma_f64(ai, Aq[(jb * 16 + lr) * DLD + ko], u[jb]);
-      }
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        ctile[(int64_t)(wave * 16 + lq + 4 * rr) * ld + jb * 16 + lr] = cin[jb][rr] - u[jb][rr];
+    for (int rr = 0; rr < 4; ++rr) ctile[(int64_t)(r0 + lq + 4 * rr) * ld + wave * 16 + lr] = cin[rr] - u[rr];
     return;
   }
   d4_t acc[2][2] = {};
@@ -792,10 +803,10 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
     if (p == 0 && c->W.p && c->diag_stamps) {  // diagnostic: phase times inside the first diagonal block
       unsigned long long *st = (unsigned long long *)c->W.p, h[20];
       if (c->diag_variant == 0)
-        hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+        hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(nb > 1 ? 2 : 1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
                            (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp, 0, 0, 0, 0, 0, nb);
       else
-        hipLaunchKernelGGL((potrf_diag_kernel<1, true>), dim3(1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+        hipLaunchKernelGGL((potrf_diag_kernel<1, true>), dim3(nb > 1 ? 2 : 1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
                            (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp, 0, 0, 0, 0, 0, nb);
       (void)hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream);
       (void)hipStreamSynchronize(c->stream);
@@ -808,12 +819,13 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
       return;
     }
     const int ns = pend.tiles;
+    const dim3 grid(1 + (p + 1 < nb ? 1 : 0) + nt + ns);  // factor, copier of the tile below, riders
     if (c->diag_variant == 0)
-      hipLaunchKernelGGL(potrf_diag_kernel<0>, dim3(1 + nt + ns), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+      hipLaunchKernelGGL(potrf_diag_kernel<0>, grid, dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
                          (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp, nt,
                          pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
     else
-      hipLaunchKernelGGL(potrf_diag_kernel<1>, dim3(1 + nt + ns), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+      hipLaunchKernelGGL(potrf_diag_kernel<1>, grid, dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
                          (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp, nt,
                          pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
     pend.tiles = 0;
@@ -825,9 +837,9 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
   auto trsm = [&](int p, bool near) {
     const int ntrsm = nb - p - 1, nx = with_inverse ? 4 * nb : 0;  // 4 column slabs per tile of the inverse row
     if (ntrsm + nx <= 0) return;
-    if (near)
-      hipLaunchKernelGGL(potrf_trsm_kernel<true>, dim3(ntrsm + nx), dim3(256), NEAR_LDS_BYTES, c->stream, L, n, p,
-                         (const double *)c->dinv.p, ntrsm, nb, (double *)c->Linv.p, (const double *)Wp);
+    if (near)  // four 16-row slabs per tile
+      hipLaunchKernelGGL(potrf_trsm_kernel<true>, dim3(4 * ntrsm + nx), dim3(256), NEAR_LDS_BYTES, c->stream, L, n, p,
+                         (const double *)c->dinv.p, 4 * ntrsm, nb, (double *)c->Linv.p, (const double *)Wp);
     else
       hipLaunchKernelGGL(potrf_trsm_kernel<false>, dim3(ntrsm + nx), dim3(256), TRSM_LDS_BYTES, c->stream, L, n, p,
                          (const double *)c->dinv.p, ntrsm, nb, (double *)c->Linv.p, (const double *)Wp);
