@@ -398,24 +398,27 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   // doubling level 32 -> 64: T = L[32:64, 0:32] * X[0:32, 0:32]; X[32:64, 0:32] = -X[32:64, 32:64] * T
   {
+    // Static trip counts (the skipped 16-blocks of the triangular operands are exact zeros in LDS, so running
+    // over them changes nothing) and two accumulators per product: all operand loads issue up front and the
+    // MFMA chains are half as deep.
     const int ti = wave >> 1, tj = wave & 1;
-    d4_t t = {0.0, 0.0, 0.0, 0.0};
-    for (int kt = tj; kt < 2; ++kt)
+    d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        t = mfma_f64(A[(32 + ti * 16 + lr) * DLD + kt * 16 + 4 * s4 + lq],
-                     X[(kt * 16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t);
+    for (int s4 = 0; s4 < 4; ++s4) {
+      t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
+      t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+    }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t[rr];
+    for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
     __syncthreads();
-    d4_t xx = {0.0, 0.0, 0.0, 0.0};
-    for (int kt = 0; kt <= ti; ++kt)
+    d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        xx = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 32 + kt * 16 + 4 * s4 + lq],
-                      T[(kt * 16 + 4 * s4 + lq) * TLD + tj * 16 + lr], xx);
+    for (int s4 = 0; s4 < 4; ++s4) {
+      x0 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 32 + 4 * s4 + lq], T[(4 * s4 + lq) * TLD + tj * 16 + lr], x0);
+      x1 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 48 + 4 * s4 + lq], T[(16 + 4 * s4 + lq) * TLD + tj * 16 + lr], x1);
+    }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = xx[rr];
+    for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = x0[rr] + x1[rr];
   }
   __syncthreads();
   B7_DIAG_STAMP(18);
