@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256)
         x[j] = rhs[j] - sacc;
         xs[j] = x[j] * r;
       });
-      const unsigned long long badmask = __ballot(!(dmine > 0.0)) & 0xFFFFull;  // also NaN, like dpotrf's test
+      // also NaN, like dpotrf's test; a subnormal pivot counts as failed too (its reciprocal overflows)
+      const unsigned long long badmask = __ballot(!(dmine >= 2.2250738585072014e-308)) & 0xFFFFull;
       if (badmask != 0 && lane == 0 && info[0] == 0) info[0] = p * NB + o + __ffsll((long long)badmask);
       double ymine = __builtin_amdgcn_rsq(dmine);  // 1/sqrt(d_lr): hardware estimate + two Newton steps
       const double hp = 0.5 * dmine;

@@ -110,7 +110,8 @@ int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
  * added to the ORIGINAL diagonal until success, or chol(I) once eps > ||K||_F); alpha = K^-1 (Y - mean).
  * X_obs N x d (d <= 96), Y_obs N x ycols (ycols <= 256: fantasy columns share K, L and differ only in alpha).
  * Outputs (all nullable): nll_out[ycols] negative log marginal likelihood,
- * jitter_used (0 = none, -1 = fell back to chol(I)), info = 1-based first failing pivot of the FIRST
+ * jitter_used (0 = none, -1 = fell back to chol(I)), info = 1-based first failing pivot (not > 0, NaN, or below
+ * the smallest normal double) of the FIRST
  * attempt (0 = positive definite). */
 int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp,
               double *nll_out, double *jitter_used, int *info);
