@@ -86,7 +86,8 @@ struct b7_ctx {
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
   int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
-  int post_variant = 7;  // tile/occupancy variant of post_kernel (B7_POST_VARIANT overrides; see posterior.hip)
+  int post_variant = 9;  // posterior.hip launch_post: 9 = 128x256 tile, 8 waves, odd LDS stride, zero-strip skip, static
+                         // priority raise for the younger half of the waves (B7_POST_VARIANT overrides)
   DevBuf part;   // argmax partials (value, index)
   DevBuf scratch; // misc (fmin upload, results)
   DevBuf tmpgrid; // predict_at temporary grid

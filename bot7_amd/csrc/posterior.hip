@@ -24,7 +24,7 @@
 namespace {
 
 // BM = rows of L^-1 per n-tile, BN = candidates per block, WM x WN waves of 64x64 accumulators each.
-template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI>
+template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI, bool PRIO = false>
 __global__ void __launch_bounds__(64 * WM * WN, MINW)
     post_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0,
                 int64_t Mtotal, double base, double sgn, double var_add, int clamp, double var_min,
@@ -35,6 +35,10 @@ __global__ void __launch_bounds__(64 * WM * WN, MINW)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double *B = ks + (int64_t)blockIdx.x * BN * Npad;  // this block's BN candidate rows of K*
   double colss[GP::TN] = {};
+  // PRIO: with two waves per SIMD the second-dispatched half of the workgroup loses issue arbitration to the older
+  // half at the start of every stage; one static priority raise for that half evens it out (the condition must be
+  // wave-uniform for the scalar s_setprio to be conditional at all)
+  if (PRIO && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 32 * WM * WN) __builtin_amdgcn_s_setprio(1);
 
   const int ntiles = Npad / BM;
   for (int t = 0; t < ntiles; ++t) {
@@ -75,10 +79,10 @@ __global__ void __launch_bounds__(64 * WM * WN, MINW)
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI>
+template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI, bool PRIO = false>
 int launch_post_variant(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
   using GP = GemmF64<BM, BN, 16, WM, WN, false, PAD>;
-  auto kern = post_kernel<BM, BN, WM, WN, MINW, PAD, TRI>;
+  auto kern = post_kernel<BM, BN, WM, WN, MINW, PAD, TRI, PRIO>;
   const int lds = GP::LDS_BYTES;
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const bool blr = c->model_kind == 1;
@@ -95,7 +99,7 @@ int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t
   PhaseScope ps(c, "post");
   if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
   int v = c->post_variant;
-  if ((v == 2 || v == 8) && (c->Npad % 256)) v = 7;
+  if ((v == 2 || v == 8) && (c->Npad % 256)) v = 9;
   switch (v) {
     case 0: return launch_post_variant<128, 128, 2, 2, 1, 2, false>(c, ks, row0, rows, Mtotal, var);  // 1 wave/SIMD
     case 2: return launch_post_variant<256, 128, 4, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, tall
@@ -105,6 +109,7 @@ int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t
     case 6: return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both
     case 7: return launch_post_variant<128, 256, 2, 4, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, wide
     case 8: return launch_post_variant<256, 128, 4, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, tall
+    case 9: return launch_post_variant<128, 256, 2, 4, 2, 1, true, true>(c, ks, row0, rows, Mtotal, var);  // 7 + priority
     default: return launch_post_variant<128, 128, 2, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var); // 2 blocks/CU
   }
 }
