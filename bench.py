@@ -90,7 +90,7 @@ def cpu_baseline(d, N, objective, score, sample, X_obs, Y, hyp):
 def pmc_traffic(rows_per_launch, N):
     """HBM bytes per post_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, + WRITE_SIZE), when they were taken at this launch shape; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r01z_pmc_summary.json")
     try:
         with open(path) as f:
             p = json.load(f)
@@ -255,7 +255,7 @@ def main():
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS if achieved == achieved else None,
                      "traffic": pmc_traffic(rows_per_launch, N),
-                     "traffic_source": "profiles/r01d_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                     "traffic_source": "profiles/r01z_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                        "passes of this bench at the same launch shape; K* is re-read ~8.5x by design, "
                                        "algorithmic bytes per launch = rows*N*8)",
                      "algorithmic_bytes_per_launch": rows_per_launch * N * 8.0,
