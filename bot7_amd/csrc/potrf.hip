@@ -146,6 +146,18 @@ __device__ __forceinline__ void static_for(F &&f) {
 // serial factorisation.  potrf_trsm_kernel's extra workgroups finish the row: Linv[p, j] = -inv(L_pp) sum_c W[c].
 // Workgroups nt + 1.. are tiles of the previous panel group's trailing update that nothing needs before the NEXT
 // group (block columns beyond this group's own): deferred to here for the same reason.
+// A_ij -= L_i,ko L_j,ko'  for one 16x16 tile of the 64x64 block in LDS (ko = first column of the source block column)
+__device__ __forceinline__ void block16_update(double *__restrict__ A, int i, int j, int ko, int lr, int lq) {
+  d4_t c;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) c[rr] = A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+    c = mfma_f64(-A[(i * 16 + lr) * DLD + ko + 4 * s4 + lq], A[(j * 16 + lr) * DLD + ko + 4 * s4 + lq], c);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr] = c[rr];
+}
+
 template <int VAR, bool STAMP = false>
 __global__ void __launch_bounds__(256)
     potrf_diag_kernel(double *__restrict__ L, int ld, int p, double *__restrict__ dinv, int *__restrict__ info,
@@ -299,6 +311,18 @@ __global__ void __launch_bounds__(256)
         for (int k = 0; k < 16; ++k) A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
       }
     }
+    if (VAR == 1 && wave > 0 && kb > 0) {
+      // while wave 0 factors: the previous step's update of the tiles right of block column kb, with the previous
+      // step's panel (columns o - 16 ..).  kb = 1: (2,2) (3,2) (3,3); kb = 2: (3,3) again with panel 1; kb = 3: none.
+      // Nothing wave 0 touches in this phase (tile (kb,kb), the rows (i,kb) below it, X) is read or written here.
+      const int ko = o - 16;
+      if (kb == 1) {
+        const int i = wave == 1 ? 2 : 3, j = wave == 3 ? 3 : 2;
+        block16_update(A, i, j, ko, lr, lq);
+      } else if (kb == 2 && wave == 1) {
+        block16_update(A, 3, 3, ko, lr, lq);
+      }
+    }
     if (VAR == 0 && wave == 0) {
       // every 16-lane row of the wave holds the same 16x16 sub-block (lane lr = matrix row lr)
       double a[16], r[16], x[16];
@@ -363,20 +387,18 @@ __global__ void __launch_bounds__(256)
       __syncthreads();
     }
     B7_DIAG_STAMP(4 + 4 * kb);
-    // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4
-    {
+    // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4.  VAR 1 does only block column
+    // kb + 1 here (all the next factor step reads); the tiles right of it were left to waves 1..3 of the NEXT
+    // step's factor phase, where they idle anyway (see there).
+    if (VAR == 1) {
+      const int i = kb + 1 + wave;
+      if (i < 4) block16_update(A, i, kb + 1, o, lr, lq);
+    } else {
       int pidx = 0;
       for (int i = kb + 1; i < 4; ++i)
         for (int j = kb + 1; j <= i; ++j, ++pidx) {
           if ((pidx & 3) != wave) continue;
-          d4_t c;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) c[rr] = A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4)
-            c = mfma_f64(-A[(i * 16 + lr) * DLD + o + 4 * s4 + lq], A[(j * 16 + lr) * DLD + o + 4 * s4 + lq], c);
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr] = c[rr];
+          block16_update(A, i, j, o, lr, lq);
         }
     }
     __syncthreads();
