@@ -230,11 +230,14 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int e = tid + 256 * t, i = e >> 5, j2 = (e & 31) * 2;
+      // VAR 1: I_16 for the inversion recurrence lives in the block's unused upper-right 16x16 corner (rows 0..15,
+      // columns 48..63: only blocks on or below the diagonal are ever touched); its neighbour (columns 32..47)
+      // takes dummy stores
+      if (VAR == 1 && i < 16 && j2 >= 48) v[t] = make_double2(i == j2 - 48 ? 1.0 : 0.0, i == j2 - 47 ? 1.0 : 0.0);
       *reinterpret_cast<double2 *>(A + i * DLD + j2) = v[t];
       *reinterpret_cast<double2 *>(X + i * DLD + j2) = make_double2(0.0, 0.0);
     }
   }
-  if (VAR == 1 && tid < 256) T[(tid >> 4) * TLD + (tid & 15)] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;  // I_16
   __syncthreads();
   B7_DIAG_STAMP(1);
 
@@ -257,9 +260,10 @@ __global__ void __launch_bounds__(256)
       double a[16], x[16], xs[16], rhs[16];
       const int ib = kb + lq;  // sub-panel block of this lane row (lq >= 1); lane row 0 carries the inverse
       const bool has_sub = lq > 0 && ib < 4;
-      // every lane reads its right-hand side through one pointer, no selects: the identity rows live in T
-      // (written before the loop), lane rows without a block read zeros from X's upper triangle
-      const double *rsrc = (lq == 0) ? T + lr * TLD : (has_sub ? A + (ib * 16 + lr) * DLD + o : X + 48);
+      // every lane reads its right-hand side through one pointer, no selects: the identity rows live in the
+      // block's unused upper-right corner (written before the loop), lane rows without a block read zeros from X's
+      // upper triangle
+      const double *rsrc = (lq == 0) ? A + lr * DLD + 48 : (has_sub ? A + (ib * 16 + lr) * DLD + o : X + 48);
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         a[k] = A[(o + lr) * DLD + o + k];
@@ -301,8 +305,8 @@ __global__ void __launch_bounds__(256)
         x[k] *= yk;  // lane row 0: inv(L)[k][lr] = s_k / sqrt(d_k); lane rows 1..3: L_ik[lr][k]
       });
       // one store loop for all lanes: lane row 0 writes its column of inv(L_kk) (stride DLD), rows 1..3 their
-      // solved sub-panel row (stride 1), rows without a block into T's spare columns (never read)
-      double *wdst = (lq == 0) ? X + o * DLD + o + lr : (has_sub ? A + (ib * 16 + lr) * DLD + o : T + lr * TLD + 16);
+      // solved sub-panel row (stride 1), rows without a block into an unused upper block of A (never read)
+      double *wdst = (lq == 0) ? X + o * DLD + o + lr : (has_sub ? A + (ib * 16 + lr) * DLD + o : A + lr * DLD + 32);
       const int wstride = (lq == 0) ? DLD : 1;
 #pragma unroll
       for (int k = 0; k < 16; ++k) wdst[k * wstride] = x[k];
@@ -321,6 +325,30 @@ __global__ void __launch_bounds__(256)
         block16_update(A, i, j, ko, lr, lq);
       } else if (kb == 2 && wave == 1) {
         block16_update(A, 3, 3, ko, lr, lq);
+      } else if (kb == 2 && wave == 2) {
+        // inverse doubling 16 -> 32 of the pair (0,1): X_10 = -inv(L_11) * (L_10 * inv(L_00)); its inputs are final
+        d4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(A[(16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + lr], t);
+        d4_t xx = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) xx = mfma_f64(-X[(16 + lr) * DLD + 16 + 4 * s4 + lq], t[s4], xx);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) X[(16 + lq + 4 * rr) * DLD + lr] = xx[rr];
+      } else if (kb == 3) {
+        // first half of the doubling 32 -> 64: T = L[32:64, 0:32] * X[0:32, 0:32] (both final since step 2);
+        // tiles (ti, tj): wave 1 (0,0) and (0,1), wave 2 (1,0), wave 3 (1,1)
+        for (int q = 0; q < (wave == 1 ? 2 : 1); ++q) {
+          const int ti = wave == 1 ? 0 : 1, tj = wave == 1 ? q : wave - 2;
+          d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
+            t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
+        }
       }
     }
     if (VAR == 0 && wave == 0) {
@@ -405,9 +433,10 @@ __global__ void __launch_bounds__(256)
     B7_DIAG_STAMP(5 + 4 * kb);
   }
 
-  // doubling level 16 -> 32: pairs (0,1) and (2,3), one per wave; X_10 = -inv(L_11) * (L_10 * inv(L_00))
-  if (wave < 2) {
-    const int a0 = wave * 32, c0 = a0 + 16;
+  // What is left of the inverse doubling (VAR 1 did the pair (0,1) and T = L[32:64,0:32] X[0:32,0:32] inside the
+  // loop, on waves that were idle): the pair (2,3), then X[32:64, 0:32] = -X[32:64, 32:64] * T.
+  if (VAR == 1 ? wave == 0 : wave < 2) {
+    const int a0 = (VAR == 1 ? 1 : wave) * 32, c0 = a0 + 16;
     d4_t t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
@@ -419,21 +448,19 @@ __global__ void __launch_bounds__(256)
     for (int rr = 0; rr < 4; ++rr) X[(c0 + lq + 4 * rr) * DLD + a0 + lr] = xx[rr];
   }
   __syncthreads();
-  // doubling level 32 -> 64: T = L[32:64, 0:32] * X[0:32, 0:32]; X[32:64, 0:32] = -X[32:64, 32:64] * T
   {
-    // Static trip counts (the skipped 16-blocks of the triangular operands are exact zeros in LDS, so running
-    // over them changes nothing) and two accumulators per product: all operand loads issue up front and the
-    // MFMA chains are half as deep.
     const int ti = wave >> 1, tj = wave & 1;
-    d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+    if (VAR == 0) {
+      d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
-      t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
+        t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
+      __syncthreads();
     }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
-    __syncthreads();
     d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
