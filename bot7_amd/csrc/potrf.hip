@@ -832,18 +832,25 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
   hipLaunchKernelGGL(copy_lower_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                      (const double *)c->K.p, L, n, c->N, extra);
   B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K64::STAGE_DOUBLES * 8));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K128::STAGE_DOUBLES * 8));
+  if (!c->potrf_attrs_set) {  // once per context: every one of these is a host API call
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K64::STAGE_DOUBLES * 8));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K128::STAGE_DOUBLES * 8));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trsm_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trsm_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, NEAR_LDS_BYTES));
+    c->potrf_attrs_set = true;
+  }
   // panels in pairs (a, b = a + 1): the narrow update of block column b after panel a, then ONE trailing update
   // with both panels (K = 128) for everything to the right of b.
   // deferred part of the previous group's trailing update: (kc0, kb, j0, ncols), taken by the next diag launch
@@ -883,10 +890,6 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
                          pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
     pend.tiles = 0;
   };
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trsm_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trsm_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, NEAR_LDS_BYTES));
   auto trsm = [&](int p, bool near) {
     const int ntrsm = nb - p - 1, nx = with_inverse ? 4 * nb : 0;  // 4 column slabs per tile of the inverse row
     if (ntrsm + nx <= 0) return;
