@@ -100,6 +100,9 @@ int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t
   if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
   int v = c->post_variant;
   if ((v == 2 || v == 8) && (c->Npad % 256)) v = 9;
+  // fewer 256-candidate workgroups than CUs: the 128-wide tile fills the chip (N = 2048, M = 32768: 2.6 vs 4.2 ms;
+  // N = 256: 63 vs 83 us); a 64-wide one was slower again (4.1 ms)
+  if (v == 9 && rows / 256 < c->cus) v = 6;
   switch (v) {
     case 0: return launch_post_variant<128, 128, 2, 2, 1, 2, false>(c, ks, row0, rows, Mtotal, var);  // 1 wave/SIMD
     case 2: return launch_post_variant<256, 128, 4, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, tall
