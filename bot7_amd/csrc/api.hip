@@ -49,19 +49,48 @@ void b7_release(DevBuf &b) {
   b.cap = 0;
 }
 
+static hipEvent_t phase_event(b7_ctx *c) {
+  if (!c->free_events.empty()) {
+    hipEvent_t e = c->free_events.back();
+    c->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+// Turn the recorded event pairs into phase times (one stream synchronisation) and recycle the events.
+static void resolve_phases(b7_ctx *c) {
+  if (c->pending.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (const b7_ctx::PendingPhase &p : c->pending) {
+    float ms = 0.f;
+    if (p.e0 && p.e1 && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      PhaseStat &s = c->phases[p.name];
+      s.ms += ms;
+      s.launches += 1;
+    }
+    if (p.e0) c->free_events.push_back(p.e0);
+    if (p.e1) c->free_events.push_back(p.e1);
+  }
+  c->pending.clear();
+}
+
+// Phases do not nest.  Recording costs two hipEventRecord calls and no synchronisation: a profiled step keeps the
+// host running ahead of the GPU exactly like an unprofiled one.
 PhaseScope::PhaseScope(b7_ctx *c_, const char *name_) : c(c_), name(name_) {
-  if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
+  if (!c->profile) return;
+  c->phase_e0 = phase_event(c);
+  if (c->phase_e0) (void)hipEventRecord(c->phase_e0, c->stream);
 }
 PhaseScope::~PhaseScope() {
-  if (!c->profile) return;
-  (void)hipEventRecord(c->pev[1], c->stream);
-  (void)hipEventSynchronize(c->pev[1]);
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, c->pev[0], c->pev[1]) == hipSuccess) {
-    PhaseStat &s = c->phases[name];
-    s.ms += ms;
-    s.launches += 1;
-  }
+  if (!c->profile || !c->phase_e0) return;
+  hipEvent_t e1 = phase_event(c);
+  if (e1) (void)hipEventRecord(e1, c->stream);
+  c->pending.push_back({name, c->phase_e0, e1});
+  c->phase_e0 = nullptr;
+  if (c->pending.size() >= 4096) resolve_phases(c);  // bound the pool in long profiled loops
 }
 
 static double *cur_grid(b7_ctx *c) { return (double *)c->grid[c->grid_cur].p; }
@@ -114,8 +143,6 @@ int b7_create(b7_ctx **out, int device_id) {
     if (g >= 1 && g <= 8) c->potrf_group = g;
   }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreate(&c->pev[0]);
-  if (e == hipSuccess) e = hipEventCreate(&c->pev[1]);
   if (e != hipSuccess) {
     delete c;
     return b7_fail(nullptr, B7_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
@@ -143,8 +170,9 @@ void b7_destroy(b7_ctx *c) {
       (void)hipEventDestroy(c->tev[i][0]);
       (void)hipEventDestroy(c->tev[i][1]);
     }
-  (void)hipEventDestroy(c->pev[0]);
-  (void)hipEventDestroy(c->pev[1]);
+  resolve_phases(c);
+  for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+  if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -985,12 +1013,14 @@ int b7_profile_enable(b7_ctx *c, int on) {
 
 int b7_profile_reset(b7_ctx *c) {
   if (!c) return B7_ERR_INVALID;
+  resolve_phases(c);
   c->phases.clear();
   return B7_OK;
 }
 
 int b7_profile_get(b7_ctx *c, const char *phase, double *ms_total, int64_t *launches) {
   if (!c || !phase) return B7_ERR_INVALID;
+  resolve_phases(c);
   auto it = c->phases.find(phase);
   if (ms_total) *ms_total = it == c->phases.end() ? 0.0 : it->second.ms;
   if (launches) *launches = it == c->phases.end() ? 0 : it->second.launches;

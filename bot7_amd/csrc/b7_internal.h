@@ -105,7 +105,12 @@ struct b7_ctx {
   bool tev_init = false;
   bool profile = false;
   std::map<std::string, PhaseStat> phases;
-  hipEvent_t pev[2];
+  // phase profiling without host synchronisation: event pairs are recorded into `pending` and turned into times
+  // when somebody asks (b7_profile_get / _reset), after one stream synchronisation; events are recycled
+  struct PendingPhase { const char *name; hipEvent_t e0, e1; };
+  std::vector<PendingPhase> pending;
+  std::vector<hipEvent_t> free_events;
+  hipEvent_t phase_e0 = nullptr;  // start event of the phase being recorded
 };
 
 // ---- error helpers ---------------------------------------------------------------------------------
