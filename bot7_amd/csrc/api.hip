@@ -143,9 +143,13 @@ int b7_create(b7_ctx **out, int device_id) {
     if (g >= 1 && g <= 8) c->potrf_group = g;
   }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 4096, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0);
   if (e != hipSuccess) {
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-    return b7_fail(nullptr, B7_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
+    return b7_fail(nullptr, B7_ERR_HIP, "stream / pinned result block creation: %s", hipGetErrorString(e));
   }
   // fixed scratch: [0,1K) lengthscales, [2K,4K) fmin, [4K,...) Sobol table + mins/maxes; never regrown
   if (b7_ensure(c, c->scratch, 64 * 1024) != B7_OK) {
@@ -171,6 +175,7 @@ void b7_destroy(b7_ctx *c) {
       (void)hipEventDestroy(c->tev[i][1]);
     }
   resolve_phases(c);
+  if (c->pinned) (void)hipHostFree(c->pinned);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
   (void)hipStreamDestroy(c->stream);
@@ -375,7 +380,9 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   // inverse came out of the factorisation itself, alpha and the likelihood terms do not need the host, and one
   // small copy (info + terms) with one synchronisation ends the fit.  A failed pivot (rare) falls back to the
   // jitter schedule and redoes the tail.
-  struct { int info[4]; double terms[257]; } blk;
+  struct FitBlock { int info[4]; double terms[257]; };
+  static_assert(sizeof(FitBlock) <= 2304, "the fit report shares the 4 KiB pinned block with the arg-max result");
+  FitBlock &blk = *static_cast<FitBlock *>(c->pinned);  // pinned: the copy needs no pageable staging
   double *terms_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(c->info.p) + 16);
   const size_t blk_bytes = 16 + sizeof(double) * (nll_out ? 1 + ycols : 0);
   B7_TRY(launch_potrf(c, 0.0, true));

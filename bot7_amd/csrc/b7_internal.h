@@ -75,6 +75,10 @@ struct b7_ctx {
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
   int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
                            // Npad <= 8192, 2 always (B7_INVERSE_INLINE)
+  // 4 KiB of pinned, device-mapped host memory for the small result blocks (fit report, arg-max): kernels write
+  // them directly or a copy lands without pageable staging; read after a stream synchronisation
+  void *pinned = nullptr;
+  void *pinned_dev = nullptr;
   bool potrf_attrs_set = false;  // dynamic-LDS limits of the Cholesky kernels raised (once per context)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
   bool diag_stamps = false, syrk_stamps = false;  // diagnostics: s_memtime phase stamps (B7_DIAG_STAMPS, B7_SYRK_STAMPS)

@@ -182,10 +182,11 @@ int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *bes
   B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
   Best *part = (Best *)c->part.p;
   hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, c->stream, acc, M, divisor, part);
-  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb, part + nb);
+  // the final (value, index) goes straight into pinned, device-mapped host memory: no copy, just the synchronisation
+  Best *res_dev = reinterpret_cast<Best *>(static_cast<char *>(c->pinned_dev) + 2304);
+  const Best &h = *reinterpret_cast<const Best *>(static_cast<const char *>(c->pinned) + 2304);
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb, res_dev);
   B7_HIP(c, hipGetLastError());
-  Best h;
-  B7_HIP(c, hipMemcpyAsync(&h, part + nb, sizeof(Best), hipMemcpyDeviceToHost, c->stream));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   if (best_val) *best_val = h.v;
   if (best_idx1) *best_idx1 = h.i + 1;
