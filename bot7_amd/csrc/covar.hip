@@ -27,20 +27,42 @@
 namespace {
 
 // ---- observation pre-scaling: zsc = z .* w (padded), zsh = (sum z^2 w)/2 ---------------------------------------
-__global__ void __launch_bounds__(256) prep_obs_kernel(const double *__restrict__ xobs, const double *__restrict__ ls,
-                                                       double *__restrict__ w, double *__restrict__ zsc,
-                                                       double *__restrict__ zsh, int N, int Npad, int d, int dpad) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < dpad) w[i] = (i < d) ? 1.0 / ls[i] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
-  if (i >= Npad) return;
+// One wave per 64 observations: the rows are loaded and stored through an LDS tile (coalesced both ways; a thread
+// walking its own row in global memory was 16 us at N = 2048), the weights 1/ls are formed once per workgroup, and
+// each lane sums its row in ascending k exactly as before (same bits).
+__global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__ xobs, const double *__restrict__ ls,
+                                                      double *__restrict__ w, double *__restrict__ zsc,
+                                                      double *__restrict__ zsh, int N, int Npad, int d, int dpad) {
+  extern __shared__ __align__(16) double psm[];
+  const int tld = dpad + 1, lane = threadIdx.x, row0 = blockIdx.x * 64;
+  double *tile = psm, *wl = psm + 64 * tld;
+  for (int k = lane; k < dpad; k += 64) {
+    const double wk = (k < d) ? 1.0 / ls[k] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
+    wl[k] = wk;
+    if (blockIdx.x == 0) w[k] = wk;
+  }
+  int nrows = N - row0;
+  nrows = nrows < 0 ? 0 : (nrows > 64 ? 64 : nrows);
+  const double *src = xobs + (int64_t)row0 * d;
+  for (int e = lane; e < nrows * d; e += 64) {
+    const int r = e / d, k = e - r * d;
+    tile[r * tld + k] = src[e];
+  }
+  __syncthreads();
   double s = 0.0;
   for (int k = 0; k < dpad; ++k) {
-    double z = (i < N && k < d) ? xobs[(int64_t)i * d + k] : 0.0;
-    double wk = (k < d) ? 1.0 / ls[k] : 0.0;
-    zsc[(int64_t)i * dpad + k] = z * wk;
+    const double z = (lane < nrows && k < d) ? tile[lane * tld + k] : 0.0;
+    const double wk = wl[k];
+    tile[lane * tld + k] = z * wk;
     s += (z * z) * wk;  // Z_ss = (Z.^2) * inv_ls, :79
   }
-  zsh[i] = (i < N) ? 0.5 * s : __builtin_inf();
+  if (row0 + lane < Npad) zsh[row0 + lane] = (lane < nrows) ? 0.5 * s : __builtin_inf();
+  __syncthreads();
+  double *dst = zsc + (int64_t)row0 * dpad;
+  for (int e = lane; e < 64 * dpad; e += 64) {
+    const int r = e / dpad, k = e - r * dpad;
+    if (row0 + r < Npad) dst[e] = tile[r * tld + k];
+  }
 }
 
 // exp(x) for x <= 0 (or NaN): k = rint(x log2 e), r = x - k ln2 in two pieces, Taylor to r^13 (|r| <= ln2/2:
@@ -288,9 +310,9 @@ int ksx_dispatch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t M
 }  // namespace
 
 int launch_prep_obs(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int d) {
-  int n = c->Npad > c->dpad ? c->Npad : c->dpad;
-  hipLaunchKernelGGL(prep_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, xobs, ls_dev, (double *)c->w.p,
-                     (double *)c->zsc.p, (double *)c->zss.p, N, c->Npad, d, c->dpad);
+  const size_t lds = sizeof(double) * (64 * (size_t)(c->dpad + 1) + c->dpad);
+  hipLaunchKernelGGL(prep_obs_kernel, dim3((c->Npad + 63) / 64), dim3(64), lds, c->stream, xobs, ls_dev,
+                     (double *)c->w.p, (double *)c->zsc.p, (double *)c->zss.p, N, c->Npad, d, c->dpad);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -299,8 +321,8 @@ int launch_prep_obs(b7_ctx *c, const double *xobs, const double *ls_dev, int N, 
 // with the same values.
 int launch_prep_obs_aux(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int npad, double *zsc,
                         double *zsh) {
-  int n = npad > c->dpad ? npad : c->dpad;
-  hipLaunchKernelGGL(prep_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, xobs, ls_dev, (double *)c->w.p,
+  const size_t lds = sizeof(double) * (64 * (size_t)(c->dpad + 1) + c->dpad);
+  hipLaunchKernelGGL(prep_obs_kernel, dim3((npad + 63) / 64), dim3(64), lds, c->stream, xobs, ls_dev, (double *)c->w.p,
                      zsc, zsh, N, npad, c->dfit, c->dpad);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
