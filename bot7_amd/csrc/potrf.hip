@@ -96,13 +96,14 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- 64x64 diagonal block: factor and invert, blocked by 16 -----------------------------------------------------
-// The serial part of the whole Cholesky.  Per 16-wide sub-block kb: wave 0 factors the 16x16 diagonal sub-block
-// with one matrix row per lane (16 registers), pivots and multipliers broadcast with DPP row_share (no LDS, no
-// barriers), and inverts it the same way; then the sub-panel below (x inv(L_kk)') and the trailing update inside
-// the 64x64 block run as 16x16x16 MFMA products spread over the four waves.  The 64x64 inverse is assembled from
-// the four 16x16 inverses by two doubling levels (X = -inv(C) * (B * inv(A))), again on MFMA; the f64 accumulator
-// layout (row = (l>>4)+4r) is exactly the B-operand layout of k-step r, so T = B*inv(A) feeds the second product
-// straight from registers.
+// The serial part of the whole Cholesky.  Per 16-wide sub-block kb, wave 0 factors the 16x16 diagonal sub-block with
+// one matrix row per lane (16 registers), pivots and multipliers broadcast through DPP (no LDS, no barriers); the
+// same instruction stream inverts it (lane row 0) and solves the sub-panel rows below it (lane rows 1..3).  The
+// trailing update inside the 64x64 block and the assembly of the 64x64 inverse from the four 16x16 inverses (two
+// doubling levels, X = -inv(C) * (B * inv(A))) are 16x16x16 MFMA products; VAR 1 runs as many of them as the data
+// dependences allow on waves 1..3 while wave 0 is already in the next factor step.  The f64 accumulator layout
+// (row = (l>>4)+4r) is exactly the B-operand layout of k-step r, so T = B*inv(A) feeds the second product of a
+// doubling level straight from registers.
 constexpr int DLD = NB + 2;  // LDS row stride: = 2 (mod 4) doubles -> conflict-free ds_read_b64 fragments
 constexpr int TLD = 34;
 
