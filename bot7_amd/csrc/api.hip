@@ -143,7 +143,7 @@ int b7_create(b7_ctx **out, int device_id) {
     if (g >= 1 && g <= 8) c->potrf_group = g;
   }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 4096, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 8192, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0);
   if (e != hipSuccess) {
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -167,7 +167,7 @@ void b7_destroy(b7_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf};
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp};
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
     for (int i = 0; i < B7_MAX_TIMERS; ++i) {
@@ -230,7 +230,7 @@ static int grid_copy_out(b7_ctx *c, double *out_host) {
 int b7_grid_sobol(b7_ctx *c, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
                   double *out_host) {
   if (!c) return B7_ERR_INVALID;
-  if (size < 0) return b7_fail(c, B7_ERR_INVALID, "sobol: size %lld", (long long)size);
+  if (size < 0 || skip < 0) return b7_fail(c, B7_ERR_INVALID, "sobol: size %lld skip %lld", (long long)size, (long long)skip);
   if (dims < 1 || dims >= 40)  // assert(C.dims and C.dims < C.max_dims), grids/sobol.lua:36
     return b7_fail(c, B7_ERR_RANGE, "sobol: dims %d not in [1, 39] (grids/sobol.lua:36)", dims);
   if ((mins == nullptr) != (maxes == nullptr))
@@ -381,7 +381,7 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   // small copy (info + terms) with one synchronisation ends the fit.  A failed pivot (rare) falls back to the
   // jitter schedule and redoes the tail.
   struct FitBlock { int info[4]; double terms[257]; };
-  static_assert(sizeof(FitBlock) <= 2304, "the fit report shares the 4 KiB pinned block with the arg-max result");
+  static_assert(sizeof(FitBlock) <= 2304, "pinned block: [0, 2304) fit report, [2304, ..) arg-max result, [4096, 6144) fmin");
   FitBlock &blk = *static_cast<FitBlock *>(c->pinned);  // pinned: the copy needs no pageable staging
   double *terms_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(c->info.p) + 16);
   const size_t blk_bytes = 16 + sizeof(double) * (nll_out ? 1 + ycols : 0);
@@ -641,10 +641,11 @@ int b7_gp_append(b7_ctx *c, const double *x_new, const double *y_new) {
   double *ls_dev = (double *)c->scratch.p;  // lengthscales of the current fit
   B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N + 1, d));
   // k = K(x_new, [X; x_new]) through the covariance kernel (row 0 of a 64-row launch)
-  B7_TRY(b7_ensure(c, c->fant, sizeof(double) * ((size_t)64 * np + 4 * (size_t)np + (size_t)np * 16 + 64)));
+  const size_t nslices = ((size_t)np + 255) / 256;  // slice partials of launch_append_vectors: nslices x np
+  B7_TRY(b7_ensure(c, c->fant, sizeof(double) * ((size_t)64 * np + 4 * (size_t)np + (size_t)np * nslices + 64)));
   double *krows = (double *)c->fant.p, *lvec = krows + (size_t)64 * np, *uvec = lvec + np, *evec = uvec + np;
   double *part = evec + np;
-  int *status_dev = (int *)(part + (size_t)np * 16);
+  int *status_dev = (int *)(part + (size_t)np * nslices);
   B7_TRY(launch_ksx(c, (const double *)c->xobs.p + (size_t)N * d, 0, 64, 1, d, krows, nullptr, 1));
   B7_TRY(launch_append_vectors(c, krows, lvec, uvec, part, evec));
   B7_TRY(launch_append_finalize(c, krows, lvec, uvec, evec, status_dev));
@@ -904,8 +905,18 @@ int b7_score_ei(b7_ctx *c, const double *fmin, double tradeoff) {
   if (!fmin) return b7_fail(c, B7_ERR_INVALID, "score_ei: fmin is NULL");
   B7_TRY(score_ready(c, "score_ei"));
   B7_HIP(c, hipSetDevice(c->device));
+  // fmin goes pageable -> pinned staging ([4096, 6144) of the pinned block) -> device: the caller's array need not
+  // outlive this call and the copy is a true asynchronous one.  The staging slot may still be the source of an
+  // earlier copy in flight, hence the wait when the values change (once per nomination: fmin is the same for every
+  // hyper sample of a marginalisation loop).
+  double *fh = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 4096);
   double *fd = (double *)((char *)c->scratch.p + 2048);
-  B7_HIP(c, hipMemcpyAsync(fd, fmin, sizeof(double) * c->ycols, hipMemcpyHostToDevice, c->stream));
+  if (!c->fmin_staged || memcmp(fh, fmin, sizeof(double) * c->ycols) != 0) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(fh, fmin, sizeof(double) * c->ycols);
+    c->fmin_staged = true;
+  }
+  B7_HIP(c, hipMemcpyAsync(fd, fh, sizeof(double) * c->ycols, hipMemcpyHostToDevice, c->stream));
   return launch_ei(c, (const double *)c->mu.p, (const double *)c->var.p, fd, tradeoff, c->M, c->ycols,
                    (double *)c->acc.p, true);
 }

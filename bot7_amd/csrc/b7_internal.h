@@ -60,6 +60,7 @@ struct b7_ctx {
   DevBuf dinv;   // (Npad/64) x 64 x 64: inverses of L's diagonal blocks
   DevBuf alpha;  // Npad x yld (0 in the padding)
   DevBuf resid;  // Npad x ycols: Y - mean, then L^-1 (Y - mean)
+  DevBuf atmp;   // launch_alpha's intermediates: t = Linv resid (Npad x ycols) + slice partials (nslices x ycols x Npad)
   DevBuf info;   // int[4]: first failing pivot (1-based), 0 if none
   DevBuf ybuf;   // N x ycols raw
 
@@ -79,6 +80,7 @@ struct b7_ctx {
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
   void *pinned_dev = nullptr;
+  bool fmin_staged = false;  // the fmin staging slot of the pinned block holds a caller's values
   bool potrf_attrs_set = false;  // dynamic-LDS limits of the Cholesky kernels raised (once per context)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
   bool diag_stamps = false, syrk_stamps = false;  // diagnostics: s_memtime phase stamps (B7_DIAG_STAMPS, B7_SYRK_STAMPS)

@@ -1078,14 +1078,16 @@ int launch_nll_terms(b7_ctx *c, double *out_dev) {
 }
 
 int launch_alpha(b7_ctx *c) {
-  PhaseScope ps(c, "alpha");
   const int n = c->Npad;
-  // resid holds Y - mean (padded with zeros); alpha is used as the intermediate t = Linv * resid target
-  double *t = (double *)c->W.p;  // W is free after trtri: reuse its first n*ycols entries
+  const int nslices = (n + TSL - 1) / TSL;
+  // t = Linv * resid (n x ycols) and the nslices x ycols x n slice partials of Linv' * t live in a buffer of their
+  // own: W (n x n) is too small for them whenever ycols * (1 + nslices) > n (e.g. 100 fantasy columns at n = 128).
+  B7_TRY(b7_ensure(c, c->atmp, sizeof(double) * (size_t)n * c->ycols * (size_t)(1 + nslices)));
+  PhaseScope ps(c, "alpha");
+  double *t = (double *)c->atmp.p;
   hipLaunchKernelGGL(trmv_lower_kernel, dim3(n / 4), dim3(256), 0, c->stream, (const double *)c->Linv.p,
                      (const double *)c->resid.p, t, n, c->ycols);
-  const int nslices = (n + TSL - 1) / TSL;
-  double *part = t + (size_t)n * c->ycols;  // W has n*n doubles: room for nslices * ycols * n partials
+  double *part = t + (size_t)n * c->ycols;
   hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices), dim3(256), 0, c->stream,
                      (const double *)c->Linv.p, (const double *)t, part, n, c->ycols);
   hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double *)part,

@@ -18,10 +18,11 @@ class DeviceGrid(np.ndarray):
         return obj
 
     def __array_finalize__(self, obj):
-        if obj is None:
-            return
-        self.ctx = getattr(obj, "ctx", None)
-        self.version = getattr(obj, "version", -1)
+        # Only the explicit constructor tags an array as "the grid resident on ctx": anything derived from it
+        # (a slice, a permutation, grid*2+0.1, a normalised copy) has different rows than the device holds and
+        # must be uploaded like a plain ndarray.
+        self.ctx = None
+        self.version = -1
 
 
 class abstract(object):

@@ -22,7 +22,8 @@ class sobol(abstract):
     def generate(self, config=None):
         config = self.config if config is None else config
         size, dims = int(config["size"]), int(config["dims"])
-        skip = int(config.get("skip") or 1)  # `config.skip or 1`, :70
+        skip = config.get("skip")
+        skip = 1 if skip is None else int(skip)  # `config.skip or 1`, :70 -- in Lua 0 is truthy: skip = 0 stays 0
         mins, maxes = config.get("mins"), config.get("maxes")
         both = mins is not None and maxes is not None
         host = self.ctx.grid_sobol(size, dims, skip, mins if both else None, maxes if both else None)

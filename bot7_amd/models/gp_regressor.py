@@ -145,20 +145,24 @@ class gp_regressor(abstract):
         Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
         key = (tuple(np.asarray(hyp["lenscale_sq"], dtype=np.float64).ravel()), hyp["amp"], hyp["noise"], hyp["mean"])
         prev = getattr(self, "_prev", None)
-        if (self.config.get("incremental", True) and prev is not None and prev["token"] == self.ctx.fit_token
+        # only a clean factor is extended: after a jittered fit (or the chol(I) fallback) the reference refactors
+        # K + eps*I in full every trial (utils/math.lua:159-218), and so do we
+        if (self.config.get("incremental", True) and prev is not None and prev.get("clean")
+                and prev["token"] == self.ctx.fit_token
                 and prev["key"] == key and X.shape[0] == prev["X"].shape[0] + 1 and Y.shape[1] == prev["Y"].shape[1]
                 and np.array_equal(X[:-1], prev["X"]) and np.array_equal(Y[:-1], prev["Y"])):
             from .._lib import Bot7HipError
             try:
                 self.ctx.gp_append(X[-1], Y[-1])
-                self._prev = {"token": self.ctx.fit_token, "key": key, "X": X.copy(), "Y": Y.copy()}
+                self._prev = {"token": self.ctx.fit_token, "key": key, "X": X.copy(), "Y": Y.copy(), "clean": True}
                 self.last_fit = {"nll": None, "jitter": 0.0, "info": 0, "incremental": True}
                 return self.last_fit
             except Bot7HipError as e:
                 if e.code != -4:   # B7_ERR_STATE: factor full or not positive definite -> rebuild below
                     raise
         self.last_fit = self.ctx.gp_fit(X, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
-        self._prev = {"token": self.ctx.fit_token, "key": key, "X": X.copy(), "Y": Y.copy()}
+        self._prev = {"token": self.ctx.fit_token, "key": key, "X": X.copy(), "Y": Y.copy(),
+                      "clean": self.last_fit["jitter"] == 0.0 and self.last_fit["info"] == 0}
         return self.last_fit
 
     def _is_resident(self, X1):

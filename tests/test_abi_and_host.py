@@ -152,3 +152,36 @@ def test_missing_library_fails_loudly(monkeypatch):
     with pytest.raises(bot7_amd.Bot7HipError) as e:
         _lib.load()
     assert "no CPU fallback" in str(e.value)
+
+
+def test_device_grid_tag_does_not_propagate_to_derived_arrays():
+    """Only the explicit constructor marks an array as "resident on ctx" (__array_finalize__ used to copy
+    ctx/version onto g*2+0.1 and g[::-1], and predict then skipped the upload)."""
+    from bot7_amd.grids.abstract import DeviceGrid
+
+    class FakeCtx(object):
+        grid_version = 5
+
+    g = DeviceGrid(np.arange(12.0).reshape(4, 3), FakeCtx(), 5)
+    assert g.ctx is not None and g.version == 5
+    for derived in (g * 2 + 0.1, g[::-1], g[1:], g.copy(), np.sqrt(g), g.T):
+        assert getattr(derived, "ctx", None) is None and getattr(derived, "version", -1) == -1
+
+
+def test_sobol_skip_zero_is_kept():
+    """`config.skip or 1` (grids/sobol.lua:70): in Lua 0 is truthy, so skip = 0 stays 0."""
+    calls = []
+
+    class FakeCtx(object):
+        grid_version = 0
+
+        def grid_sobol(self, size, dims, skip, mins, maxes):
+            calls.append(skip)
+            return np.zeros((size, dims))
+
+    for skip, want in ((None, 1), (0, 0), (7, 7)):
+        cfg = {"size": 4, "dims": 2}
+        if skip is not None:
+            cfg["skip"] = skip
+        bot7_amd.grids.sobol(cfg, context=FakeCtx())()
+        assert calls[-1] == want

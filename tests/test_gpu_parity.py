@@ -866,3 +866,63 @@ def test_gp_append_matches_full_refit(ctx, orc):
     assert model.last_fit.get("incremental")
     model.fit(X_obs[:62], Y[:62], dict(hyp, amp=hyp["amp"] * 1.1))   # hypers changed -> rebuild
     assert not model.last_fit.get("incremental")
+
+
+# ---- round-2 regressions ---------------------------------------------------------------------
+@pytest.mark.parametrize("N,c", [(70, 100), (70, 256), (128, 65), (300, 200)])
+def test_multi_column_alpha_on_a_fresh_context(orc, N, c):
+    """launch_alpha's intermediates (n*c*(1 + ceil(n/256)) doubles) used to live in W (n*n doubles): too small
+    whenever c*(1+ceil(n/256)) > n.  A FRESH context has no buffer grown by an earlier big fit to hide behind."""
+    import bot7_amd
+    fresh = bot7_amd.Context(0)
+    try:
+        X_obs, Y1, X_hid, hyp = make_problem(None, orc, 6, N, 300, B.hartmann6)
+        Y = Y1 + 0.1 * np.random.default_rng(c).normal(size=(N, c))
+        out = fresh.gp_fit(X_obs, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+        f = orc.gp.fit(X_obs, Y, **hyp)
+        assert np.allclose(out["nll"], f.nll, rtol=1e-9, atol=1e-7)
+        L, alpha, Linv = fresh.gp_download(N, c)
+        assert np.allclose(alpha, f.alpha, rtol=1e-6, atol=1e-6 * np.abs(f.alpha).max())
+        assert np.allclose(L, f.L, rtol=1e-9, atol=1e-12)          # neighbours of the old scratch are intact
+        assert np.allclose(Linv @ f.L, np.eye(N), atol=1e-8)
+        fresh.grid_upload(X_hid)
+        mu, var = fresh.gp_predict()
+        mu_o, var_o = orc.gp.predict(f, X_hid)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+    finally:
+        fresh.close()
+
+
+def test_derived_device_grid_is_uploaded_not_mistaken_for_resident(ctx, orc):
+    """A transformed / permuted view of the resident grid has other rows than the device holds: predict must
+    treat it like a plain ndarray."""
+    import bot7_amd
+    X_obs, Y, _, hyp = make_problem(None, orc, 6, 40, 64, B.hartmann6)
+    grid = bot7_amd.grids.sobol({"size": 500, "dims": 6}, context=ctx)()
+    model = bot7_amd.models.gp_regressor({}, context=ctx)
+    model.hyp = hyp
+    assert model._is_resident(grid)
+    for derived in (grid * 0.5, grid[::-1], grid * 2 - 0.3, grid[:500]):
+        assert not model._is_resident(derived)
+        a = model.predict(X_obs, Y, derived, hyp)
+        b = model.predict(X_obs, Y, np.array(derived), hyp)
+        assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["var"], b["var"])
+    mu_o, var_o = orc.gp.predict(orc.gp.fit(X_obs, Y, **hyp), np.asarray(grid) * 0.5)
+    a = model.predict(X_obs, Y, grid * 0.5, hyp)
+    assert relerr(a["mean"], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(a["var"], var_o) < REL
+
+
+def test_incremental_append_is_not_used_after_a_jittered_fit(ctx, orc):
+    """utils/math.lua:159-218 refactors K + eps*I in full every trial; extending a jittered factor by an un-jittered
+    row would diverge from that exactly where the arg-max is most sensitive."""
+    import bot7_amd
+    X = orc.c.sobol(40, 3, 1)
+    X[7] = X[3]                                   # duplicate observation, no noise -> singular K -> jitter
+    Y = np.sin(3.0 * X).sum(axis=1, keepdims=True)
+    hyp = dict(lenscale_sq=np.full(3, 0.4), amp=1.0, noise=0.0, mean=0.0)
+    model = bot7_amd.models.gp_regressor({}, context=ctx)
+    model.hyp = hyp
+    model.fit(X[:30], Y[:30])
+    assert model.last_fit["jitter"] > 0.0 and model.last_fit["info"] > 0
+    model.fit(X[:31], Y[:31])
+    assert not model.last_fit.get("incremental") and model.last_fit["jitter"] > 0.0
