@@ -1,20 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: EI candidates scored per second at N = 2048 observations, d = 32 (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--candidates M_PER_GPU] [--workload metric|cfg2|cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--candidates M_PER_GPU] [--workload metric|cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path for one GP hyper sample over this rank's shard of the candidate grid,
-everything resident in HBM: K(X,X) assembly + blocked Cholesky + L^-1 + alpha (the GP fit, redundantly on
-every rank), K(X*,X) assembly + posterior mean, posterior variance (the M*N^2 fp64-MFMA GEMM), EI, score:div,
-arg-max, and for N > 1 the single (value, index) exchange over RCCL.  Weak scaling: every rank owns
---candidates rows of one global Sobol grid (rank r generates rows [r*M, (r+1)*M) itself).
+One step = one pass of the hot path (bots/bayesopt.lua:56-99) over this rank's shard of the candidate grid, everything
+resident in HBM: per GP hyper sample K(X,X) assembly + blocked Cholesky + L^-1 + alpha (the GP fit, redundantly on
+every rank; only the d + 3 hypers are uploaded, the data were put on the device once with b7_gp_set_data),
+K(X*,X) assembly + posterior mean, posterior variance (the M*N^2 fp64-MFMA GEMM), EI, score:add; then score:div,
+arg-max and the single (value, index) exchange -- b7_score_finish_global: RCCL inside libbot7hip.so.  Weak scaling:
+every rank owns --candidates rows of one global candidate list.
 
-Inputs (synthetic, deterministic): candidates = Sobol points 1..M_total in the unit cube (grids/sobol.lua
-semantics, generated on the GPU); observations = the N Sobol points that follow them; Y = the reference's
-objective restated on the host (bot7_amd.benchmarks); hypers lenscale_sq = d/8, amp = var(Y), mean = mean(Y),
-noise = 1e-4*amp.
+Inputs (synthetic, deterministic): a Sobol pool of M_total + N points in the unit cube (grids/sobol.lua
+semantics, generated on the GPU; the counter-based uniform grid for d >= 40, beyond the reference's Sobol table);
+observations = pool rows 1 + k*floor((M_total+N)/N), k = 0..N-1, removed from the pool by stable deletion
+(utils/tensor.lua:158-170); candidates = the remaining M_total rows in order (so (0.5, ..., 0.5), Sobol point 1, is an
+OBSERVATION).  Rank r owns candidate rows [r*M, (r+1)*M): it generates the contiguous pool range that holds them and
+deletes the observation rows inside it (b7_grid_remove_rows).  Y = the reference's objective restated on the host
+(bot7_amd.benchmarks); hypers lenscale_sq = d/8, amp = var(Y), mean = mean(Y), noise = 1e-4*amp.
 """
 import argparse
 import json
@@ -38,6 +42,7 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; measured 74.5-77.3 (profiles/r01_mfma_f64_probe.txt)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
+PMC_SUMMARIES = ("r02_pmc_summary.json", "r01z_pmc_summary.json")  # newest first
 
 
 def parse():
@@ -49,17 +54,48 @@ def parse():
     ap.add_argument("--candidates", type=int, default=0, help="candidates per GPU (default: the workload's)")
     ap.add_argument("--samples", type=int, default=1,
                     help="GP hyper samples marginalised per step (the reference's nSamples is 10, bots/abstract.lua:67); "
-                         "the headline metric is quoted for 1")
+                         "the headline metric is quoted for 1, the S = 10 loop is reported beside it ('marginalised')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend; gloo lets several ranks share one GPU (rehearsal of the N>1 path)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the marginalised (S = 10) leg and gp_fit_ms_by_N")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="rccl (= nccl): the exchange is b7_score_finish_global, RCCL inside libbot7hip.so; gloo: ranks "
+                         "may share one GPU and exchange through torch.distributed on the CPU (rehearsal of N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=131072, help="candidates in the bounded CPU-baseline sample")
+    ap.add_argument("--workspace-mib", type=int, default=0, help="K(X*,X) chunk workspace (default: the library's)")
     return ap.parse_args()
 
 
-def cpu_baseline(d, N, objective, score, sample, X_obs, Y, hyp):
+# ---- SURVEY 8(d) input construction ------------------------------------------------------------------------------
+def pool_index(j, N, s):
+    """Pool row (0-based) of candidate j (0-based) once the N observation rows k*s have been deleted."""
+    head = N * (s - 1)
+    return (j // (s - 1)) * s + 1 + j % (s - 1) if j < head else N * s + (j - head)
+
+
+def make_inputs(ctx, d, N, M_total, lo, hi):
+    """Observations on the host, this rank's candidate rows [lo, hi) resident on the device."""
+    s = (M_total + N) // N
+    sobol = d < 40
+    gen = (lambda size, first: ctx.grid_sobol(size, d, 1 + first)) if sobol else \
+          (lambda size, first: ctx.grid_random(size, d, seed=1, row_offset=first))
+    X_obs = np.concatenate([gen(1, k * s) for k in range(N)], axis=0)
+    if hi > lo:
+        p0, p1 = pool_index(lo, N, s), pool_index(hi - 1, N, s)
+        if sobol:
+            ctx.grid_sobol(p1 - p0 + 1, d, 1 + p0, download=False)
+        else:
+            ctx.grid_random(p1 - p0 + 1, d, seed=1, row_offset=p0, download=False)
+        k0 = -(-p0 // s)                                     # first observation index with k*s >= p0
+        inside = [k * s - p0 + 1 for k in range(k0, N) if k * s <= p1]
+        if inside:
+            ctx.grid_remove_rows(inside, want_rows=False)
+        assert ctx.grid_shape()[0] == hi - lo
+    return X_obs
+
+
+def cpu_baseline(d, N, score, X_obs, Y, hyp, X_hid):
     """The oracle (port of the Torch7 CPU path: BLAS dgemm / LAPACK dpotrf / dtrtrs through numpy+scipy) timed on
-    this box's host cores on a bounded sample of the same workload: one fit + `sample` candidates scored."""
+    this box's host cores on a bounded sample of the same workload: one fit + the first len(X_hid) candidates."""
     from oracle import cport, gp
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
@@ -67,7 +103,7 @@ def cpu_baseline(d, N, objective, score, sample, X_obs, Y, hyp):
         limiter = threadpool_limits(limits=cores)
     except Exception:
         limiter = None
-    X_hid = cport.sobol(sample, d, 1)
+    sample = X_hid.shape[0]
     t0 = time.perf_counter()
     f = gp.fit(X_obs, Y, **hyp)
     t_fit = time.perf_counter() - t0
@@ -76,29 +112,31 @@ def cpu_baseline(d, N, objective, score, sample, X_obs, Y, hyp):
         s = cport.ei(mu, var, [float(Y.min())])
     else:
         s = cport.cb(mu, var)
-    idx, _ = cport.argmax_first(s)
+    idx, val = cport.argmax_first(s)
     t = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
+    if limiter is not None and hasattr(limiter, "unregister"):
+        limiter.unregister()
+    top2 = np.partition(s, -2)[-2:]
     return {"value": sample / t, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "1 GP fit (N=%d, %.3f s) + %d Sobol candidates scored with %s in %.2f s "
+            "sample": "1 GP fit (N=%d, %.3f s) + the first %d candidates of rank 0's shard scored with %s in %.2f s "
                       "(numpy/scipy OpenBLAS+LAPACK restatement of the Torch7 CPU path; not Torch7 itself)"
                       % (N, t_fit, sample, score.upper(), t),
-            "gp_fit_ms": t_fit * 1e3, "argmax1": int(idx)}
+            "gp_fit_ms": t_fit * 1e3, "argmax1": int(idx), "best_value": float(val),
+            "top2_gap": float(top2[1] - top2[0])}, s
 
 
 def pmc_traffic(rows_per_launch, N):
     """HBM bytes per post_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, + WRITE_SIZE), when they were taken at this launch shape; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01z_pmc_summary.json")
-    try:
-        with open(path) as f:
-            p = json.load(f)
-        if int(p["rows_per_launch"]) == int(rows_per_launch) and int(p["n_obs"]) == int(N):
-            return float(p["kernels"]["post_kernel"]["hbm_bytes_per_launch"])
-    except Exception:
-        pass
-    return None
+    for name in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                p = json.load(f)
+            if int(p["rows_per_launch"]) == int(rows_per_launch) and int(p["n_obs"]) == int(N):
+                return float(p["kernels"]["post_kernel"]["hbm_bytes_per_launch"]), "profiles/" + name
+        except Exception:
+            pass
+    return None, None
 
 
 def main():
@@ -110,84 +148,88 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
         args.gpus = world
+    rccl = args.backend in ("rccl", "nccl")
 
     import torch
     import torch.distributed as td
-    if args.backend == "gloo":
+    if not rccl:
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     grouped = "RANK" in os.environ  # launched by torch.distributed.run: join the group even when it has one rank
     if grouped:
-        # RCCL prints a version banner on stdout when its communicator comes up (lazily, at the first collective):
-        # keep stdout for the one JSON line by pointing fd 1 at stderr until the communicator exists.
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if args.backend == "nccl":
-                td.init_process_group("nccl", rank=rank, world_size=world,
-                                      device_id=torch.device("cuda", local_rank))
-                warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
-            else:
-                td.init_process_group("gloo", rank=rank, world_size=world)
-                warm = torch.zeros(1, dtype=torch.float64)
-            td.all_reduce(warm)
-            td.barrier()
-            if args.backend == "nccl":
-                torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        # control plane only (rendezvous, the id hand-over, the barrier of the timing contract): a gloo group on the
+        # CPU.  Every byte of the data path's one exchange goes through the C ABI.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        td.init_process_group("gloo", rank=rank, world_size=world)
 
     import bot7_amd
-    from bot7_amd import benchmarks, dist
+    from bot7_amd import _lib, benchmarks, dist
 
     d, N, M_default, obj_name, score = WORKLOADS[args.workload]
     M = args.candidates or M_default
     M_total = M * world
     ctx = bot7_amd.Context(local_rank)
     info = ctx.device_info()
+    if args.workspace_mib:
+        ctx.set_workspace(args.workspace_mib << 20)
+    if grouped and rccl:
+        # RCCL prints a banner on stdout when a communicator comes up: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            box = [_lib.comm_unique_id() if rank == 0 else None]
+            td.broadcast_object_list(box, src=0)
+            ctx.comm_init(rank, world, box[0])
+            ctx.comm_allreduce([0.0])          # first collective: brings the rings up before anything is timed
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     # ---- inputs, resident in HBM before the timed region
     shard = dist.ShardedScorer(ctx, M_total, rank, world)
-    dev = torch.device("cuda", local_rank)
-    if d < 40:
-        X_obs = ctx.grid_sobol(N, d, 1 + M_total)                  # the N points after the candidate range
-        shard.make_sobol(d, skip=1, download=False)
-    else:
-        X_obs = ctx.grid_random(N, d, seed=1, row_offset=M_total)  # same idea on the counter-based grid
-        shard.make_random(d, seed=1, download=False)
-    if obj_name == "dngo":                                         # config 5: synthetic trained basis + hartmann-like Y
+    X_obs = make_inputs(ctx, d, N, M_total, shard.lo, shard.hi)
+    if obj_name == "dngo":
+        # config 5: a fixed "trained" 3 x 50 tanh basis; responses that ARE a Bayesian linear model in those
+        # features (what DNGO assumes after training), noise sd 0.1: the head then fits, the posterior mean moves
+        # over the grid and EI at the winners is O(1e-1), not the underflow a featureless target would give
         rng = np.random.default_rng(0)
         dims = [d, 50, 50, 50]
         Wn = [rng.normal(scale=1.0 / np.sqrt(dims[i]), size=(dims[i + 1], dims[i])) for i in range(3)]
         bn = [rng.normal(scale=0.1, size=dims[i + 1]) for i in range(3)]
-        Y = benchmarks.rastrigin(X_obs)
-        alpha_p, beta, ymean = 1.0, 1.0 / (1e-2 * float(np.var(Y))), float(np.mean(Y))
+        Z0 = ctx.blr_basis(Wn, bn, "Tanh", X=X_obs)
+        Y = (Z0 @ rng.normal(size=(50, 1)) + 0.1 * rng.normal(size=(N, 1)))
+        alpha_p, beta, ymean = 1.0, 100.0, float(np.mean(Y))
+        hyp = None
     else:
         Y = benchmarks.registry[obj_name](X_obs)
         amp = float(np.var(Y))
         hyp = {"lenscale_sq": np.full(d, d / 8.0), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
+        ctx.gp_set_data(X_obs, Y)              # the data go up once; a step uploads hypers only
     fmin = [float(Y.min())]
 
-    def step():
+    def score_add():
+        ctx.score_ei(fmin, 0.0) if score == "ei" else ctx.score_cb()
+
+    def step(samples):
         if obj_name == "dngo":
             ctx.blr_fit_x(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean)
             ctx.blr_basis(Wn, bn, "Tanh")
             ctx.blr_predict(download=False)
             ctx.score_reset()
-            ctx.score_ei(fmin, 0.0) if score == "ei" else ctx.score_cb()
+            score_add()
+            div = 1.0
         else:
-            for s_i in range(args.samples):   # bots/bayesopt.lua:73-78: one fit + predict + score:add per hyper sample
+            for s_i in range(samples):        # bots/bayesopt.lua:73-78: one fit + predict + score:add per hyper sample
                 scale = 1.0 + 0.05 * s_i      # distinct hypers per sample, as a sampler would hand over
-                ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"] * scale, hyp["amp"], hyp["noise"], hyp["mean"])
+                ctx.gp_fit_hyp(hyp["lenscale_sq"] * scale, hyp["amp"], hyp["noise"], hyp["mean"])
                 ctx.gp_predict(download=False)
                 if s_i == 0:
                     ctx.score_reset()
-                ctx.score_ei(fmin, 0.0) if score == "ei" else ctx.score_cb()
-        div = 1.0 if obj_name == "dngo" else float(args.samples)
-        return shard.nominate(div, device=dev if args.backend == "nccl" else "cpu")
+                score_add()
+            div = float(samples)
+        return shard.nominate(div, device=None if rccl else "cpu")
 
     def fence():
         ctx.sync()
@@ -196,24 +238,28 @@ def main():
             td.barrier()
             torch.cuda.synchronize()
 
+    def timed(steps, samples):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b = step(samples)
+        fence()
+        el = time.perf_counter() - t0
+        if grouped:
+            t = torch.tensor([el], dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el = float(t.item())
+        return el, b
+
     for _ in range(args.warmup):
-        best = step()
+        best = step(args.samples)
     ctx.profile_enable(True)   # HIP events around every kernel phase, on the stream the kernels run on
     ctx.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        best = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, best = timed(args.steps, args.samples)
     ctx.profile_enable(False)
-    if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     phases = {}
-    for ph in ("kxx", "potrf", "trtri", "alpha", "basis", "mean", "ksx", "post", "score", "argmax"):
+    for ph in ("kxx", "potrf", "trtri", "alpha", "basis", "mean", "ksx", "post", "score", "argmax", "exchange"):
         ms, n = ctx.profile_get(ph)
         if n:
             phases[ph] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
@@ -222,7 +268,8 @@ def main():
     # dominant kernel: post_kernel.  Algorithmic flops per launch = rows_in_launch * Npad^2 (triangular L^-1
     # exploited: N^2/2 multiply-adds per candidate); rows per launch = M / launches-per-step.
     post_launches_per_step = max(1, post["launches"] // max(1, args.steps))
-    rows_per_launch = M * (1 if obj_name == "dngo" else args.samples) / post_launches_per_step
+    n_samples = 1 if obj_name == "dngo" else args.samples
+    rows_per_launch = M * n_samples / post_launches_per_step
     n_eff = 128 if obj_name == "dngo" else N   # DNGO: the "observations" of the variance GEMM are the 50 -> 128 padded features
     flops_per_launch = rows_per_launch * float(n_eff) * float(n_eff)
     post_avg_s = (post["ms_total"] / post["launches"] * 1e-3) if post["launches"] else float("nan")
@@ -231,33 +278,38 @@ def main():
     ksx_gbs = None
     if ksx:
         ksx_gbs = rows_per_launch * (8.0 * Npad + 8.0 * d) / (ksx["ms_avg"] * 1e-3) / 1e9
-    n_fits = max(1, args.steps * (1 if obj_name == "dngo" else args.samples))
+    n_fits = max(1, args.steps * n_samples)
     fit_ms = sum(phases[p]["ms_total"] for p in ("kxx", "potrf", "trtri", "alpha") if p in phases) / n_fits
+    traffic, traffic_src = pmc_traffic(rows_per_launch, N)
 
     line = {
         "metric": "EI candidates scored/sec at N=2048,d=32" if args.workload == "metric"
                   else "%s candidates scored/sec (%s)" % (score.upper(), args.workload),
-        "value": args.steps * M_total * args.samples / elapsed,   # candidate scorings per second
-        "hyper_samples_per_step": args.samples,
+        "value": args.steps * M_total * n_samples / elapsed,   # candidate scorings per second
+        "hyper_samples_per_step": n_samples,
         "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %s d=%d, N=%d obs, %d %s candidates per GPU (%d total), %s, one hyper "
-                               "sample per step = fit + K(X*,X) + posterior mean/var + score + arg-max"
+        "config": {"workload": "%s: %s d=%d, N=%d obs (strided pick from the pool, SURVEY 8d), %d %s candidates per "
+                               "GPU (%d total), %s, %d hyper sample%s per step = %s(fit + K(X*,X) + posterior "
+                               "mean/var + score:add) + score:div + arg-max%s"
                                % (args.workload, obj_name, d, N, M, "Sobol" if d < 40 else "counter-based uniform",
-                                  M_total, score.upper()),
+                                  M_total, score.upper(), n_samples, "" if n_samples == 1 else "s",
+                                  "" if n_samples == 1 else "%d x " % n_samples,
+                                  " + RCCL exchange" if world > 1 else ""),
                    "d": d, "n_obs": N, "candidates_per_gpu": M, "candidates_total": M_total, "score": score,
-                   "parallelism": "candidate-sharded x%d, fit replicated, one (value,index) RCCL exchange" % world,
+                   "parallelism": "candidate-sharded x%d, fit replicated, one (value,index) exchange "
+                                  "(b7_score_finish_global: %s)"
+                                  % (world, "ncclAllReduce inside libbot7hip.so" if rccl else "gloo rehearsal"),
                    "device": info["name"]},
         "roofline": {"bound": "mfma", "kernel": "post_kernel (posterior variance: L^-1 K*' with fused column sumsq)",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS if achieved == achieved else None,
-                     "traffic": pmc_traffic(rows_per_launch, N),
-                     "traffic_source": "profiles/r01z_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                       "passes of this bench at the same launch shape; K* is re-read ~8.5x by design, "
-                                       "algorithmic bytes per launch = rows*N*8)",
+                     "traffic": traffic,
+                     "traffic_source": ("%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at "
+                                        "the same launch shape)" % traffic_src) if traffic_src else None,
                      "algorithmic_bytes_per_launch": rows_per_launch * N * 8.0,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": post_avg_s * 1e3,
                      "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s (measured 74.5-77.3, profiles/r01_mfma_f64_probe.txt)"},
@@ -266,8 +318,55 @@ def main():
         "phases": phases,
         "best": {"value": best[0], "index1": best[1]},
     }
+
+    extras = not args.no_extras and obj_name != "dngo"
+    # ---- the reference-faithful S = 10 marginalisation loop (bots/abstract.lua:67), beside the S = 1 headline
+    if extras and args.samples == 1:
+        S = 10
+        step(S)
+        el, b10 = timed(2, S)
+        line["marginalised"] = {"samples": S, "steps": 2, "ms_per_nomination": el / 2 * 1e3,
+                                "candidate_scorings_per_s": 2 * M_total * S / el,
+                                "marginalised_candidates_per_s": 2 * M_total / el,
+                                "best": {"value": b10[0], "index1": b10[1]}}
+    # ---- GP fit (K + Cholesky + L^-1 + alpha + NLL terms) at N = 256 / 1024 / 2048: what one slice-sampler density
+    # evaluation costs (HIP-event time on the context's stream over 20 back-to-back fits, host gaps included)
+    if extras and rank == 0:
+        by_n = {}
+        for nf in (256, 1024, 2048):
+            if nf > N:
+                continue
+            ctx.gp_set_data(X_obs[:nf], Y[:nf])
+            ctx.gp_fit_hyp(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+            ctx.sync()
+            ctx.timer_start(0)
+            for _ in range(20):
+                ctx.gp_fit_hyp(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+            ctx.timer_stop(0)
+            by_n[str(nf)] = round(ctx.timer_ms(0) / 20, 4)
+        ctx.gp_set_data(X_obs, Y)
+        line["gp_fit_ms_by_N"] = by_n
+
+    # ---- CPU baseline on a bounded sample, and the arg-max check against it
     if rank == 0 and world == 1 and not args.no_cpu_baseline and obj_name != "dngo":
-        line["cpu_baseline"] = cpu_baseline(d, N, obj_name, score, args.cpu_sample, X_obs, Y, hyp)
+        sample = min(args.cpu_sample, M)
+        X_hid = ctx.grid_download(0, sample)
+        cb, s_cpu = cpu_baseline(d, N, score, X_obs, Y, hyp, X_hid)
+        # the GPU's scores for the same hypers over the same rows, arg-max over the same prefix
+        ctx.gp_fit_hyp(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        ctx.gp_predict(download=False)
+        ctx.score_reset()
+        score_add()
+        _, _, s_gpu = ctx.score_finish(1.0, download=True)
+        gv, gi = ctx.argmax(s_gpu[:sample])
+        maxdiff = float(np.max(np.abs(s_gpu[:sample] - s_cpu)))
+        line["best_in_cpu_sample"] = {"index1": int(gi), "value": float(gv), "matches_cpu_argmax": int(gi) == cb["argmax1"],
+                                      "max_abs_score_diff_vs_cpu": maxdiff, "cpu_top2_gap": cb["top2_gap"]}
+        line["cpu_baseline"] = cb
+        if int(gi) != cb["argmax1"] and cb["top2_gap"] > 1e3 * maxdiff:
+            print(json.dumps(line))
+            sys.exit("arg-max over the CPU sample differs from the oracle's (%d vs %d) with a top-2 gap of %g"
+                     % (gi, cb["argmax1"], cb["top2_gap"]))
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:

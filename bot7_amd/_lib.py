@@ -13,14 +13,16 @@ _SO = os.path.join(_HERE, "libbot7hip.so")
 
 B7_OK = 0
 ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7_ERR_STATE",
-             -5: "B7_ERR_UNSUPPORTED", -6: "B7_ERR_RANGE"}
+             -5: "B7_ERR_UNSUPPORTED", -6: "B7_ERR_RANGE", -7: "B7_ERR_COMM"}
 
 # Every symbol include/bot7hip.h declares (tests check the library exports each of them).
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
-    "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove",
-    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
-    "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish", "b7_ei_compute", "b7_cb_compute", "b7_argmax",
+    "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove", "b7_grid_remove_rows",
+    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
+    "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
+    "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global",
+    "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
 
@@ -86,9 +88,12 @@ def load():
         "b7_grid_download": (i32, [vp, i64, i64, vp]),
         "b7_grid_shape": (i32, [vp, C.POINTER(i64), C.POINTER(i32)]),
         "b7_grid_remove": (i32, [vp, i64, vp]),
+        "b7_grid_remove_rows": (i32, [vp, vp, i64, vp]),
         "b7_gp_default_opts": (i32, [C.POINTER(GpOpts)]),
         "b7_gp_set_opts": (i32, [vp, C.POINTER(GpOpts)]),
         "b7_gp_fit": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(Hyp), vp, C.POINTER(dbl), C.POINTER(i32)]),
+        "b7_gp_set_data": (i32, [vp, vp, vp, i32, i32, i32]),
+        "b7_gp_fit_hyp": (i32, [vp, C.POINTER(Hyp), vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_chol": (i32, [vp, vp, i32, vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_gp_predict": (i32, [vp, vp, vp]),
         "b7_gp_predict_at": (i32, [vp, vp, i64, vp, vp]),
@@ -104,6 +109,12 @@ def load():
         "b7_score_ei": (i32, [vp, vp, dbl]),
         "b7_score_cb": (i32, [vp, dbl, i32, dbl]),
         "b7_score_finish": (i32, [vp, dbl, C.POINTER(dbl), C.POINTER(i64), vp]),
+        "b7_comm_unique_id": (i32, [vp]),
+        "b7_comm_init": (i32, [vp, i32, i32, vp]),
+        "b7_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "b7_comm_destroy": (i32, [vp]),
+        "b7_comm_allreduce_f64": (i32, [vp, vp, i32, i32]),
+        "b7_score_finish_global": (i32, [vp, dbl, i64, C.POINTER(dbl), C.POINTER(i64)]),
         "b7_ei_compute": (i32, [vp, vp, vp, vp, dbl, i64, i32, vp]),
         "b7_cb_compute": (i32, [vp, vp, vp, dbl, i32, dbl, i64, i32, vp]),
         "b7_argmax": (i32, [vp, vp, i64, C.POINTER(dbl), C.POINTER(i64)]),
@@ -228,6 +239,15 @@ class Context(object):
         self.grid_version += 1
         return row
 
+    def grid_remove_rows(self, idx1, want_rows=True):
+        """Stable deletion of several rows (1-based indices against the grid before the call)."""
+        idx = np.ascontiguousarray(np.asarray(idx1, dtype=np.int64).ravel())
+        _, d = self.grid_shape()
+        rows = np.empty((idx.size, d), dtype=np.float64) if want_rows else None
+        self._ck(self._L.b7_grid_remove_rows(self._h, _ptr(idx), idx.size, _ptr(rows)))
+        self.grid_version += 1
+        return rows
+
     # ---- model
     def gp_set_opts(self, **kw):
         o = GpOpts()
@@ -253,6 +273,30 @@ class Context(object):
         self._ck(self._L.b7_gp_fit(self._h, _ptr(X), _ptr(Y), N, d, Y.shape[1], C.byref(hyp), _ptr(nll),
                                    C.byref(jit), C.byref(info)))
         self.ycols = Y.shape[1]
+        self._data_d = d
+        self.fit_token += 1
+        return {"nll": nll, "jitter": jit.value, "info": info.value}
+
+    def gp_set_data(self, X_obs, Y_obs):
+        """Put (X_obs, Y_obs) on the device once; gp_fit_hyp then refits them under new hypers (the sampler's loop)."""
+        X = _f64(X_obs)
+        if X.ndim == 1:
+            X = X.reshape(1, -1)
+        N, d = X.shape
+        Y = _f64(Y_obs).reshape(N, -1)
+        self._ck(self._L.b7_gp_set_data(self._h, _ptr(X), _ptr(Y), N, d, Y.shape[1]))
+        self.ycols = Y.shape[1]
+        self._data_d = d
+        self.fit_token += 1
+
+    def gp_fit_hyp(self, lenscale_sq, amp, noise, mean, want_nll=False):
+        ls = _f64(lenscale_sq).ravel()
+        if ls.size != getattr(self, "_data_d", -1):
+            raise Bot7HipError(-1, "lenscale_sq must have d entries (call gp_set_data first)")
+        hyp = Hyp(ls.ctypes.data_as(C.POINTER(C.c_double)), float(amp), float(noise), float(mean))
+        nll = np.empty(self.ycols, dtype=np.float64) if want_nll else None
+        jit, info = C.c_double(), C.c_int()
+        self._ck(self._L.b7_gp_fit_hyp(self._h, C.byref(hyp), _ptr(nll), C.byref(jit), C.byref(info)))
         self.fit_token += 1
         return {"nll": nll, "jitter": jit.value, "info": info.value}
 
@@ -397,6 +441,33 @@ class Context(object):
         self._ck(self._L.b7_score_finish(self._h, float(divisor), C.byref(v), C.byref(i), _ptr(out)))
         return v.value, i.value, out
 
+    # ---- multi-GPU: the arg-max exchange over RCCL (one process per GPU, one context each)
+    def comm_init(self, rank, world, id_bytes):
+        """ncclCommInitRank on this context's GPU; id_bytes = comm_unique_id() of rank 0 (collective call)."""
+        buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+        self._ck(self._L.b7_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self._ck(self._L.b7_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_destroy(self):
+        self._ck(self._L.b7_comm_destroy(self._h))
+
+    def comm_allreduce(self, values, op="sum"):
+        """A few host doubles reduced over the communicator (control plane; doubles as a barrier)."""
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel()).copy()
+        self._ck(self._L.b7_comm_allreduce_f64(self._h, _ptr(v), v.size, {"sum": 0, "max": 1, "min": 2}[op]))
+        return v
+
+    def score_finish_global(self, divisor=1.0, global_row_offset=0):
+        """score:div + score:max(1) over the candidates of ALL ranks -> (value, 1-based global index)."""
+        v, i = C.c_double(), C.c_int64()
+        self._ck(self._L.b7_score_finish_global(self._h, float(divisor), int(global_row_offset), C.byref(v),
+                                                C.byref(i)))
+        return v.value, i.value
+
     def ei_compute(self, mean, var, fmin, tradeoff=0.0):
         mean = _f64(mean)
         M = mean.shape[0]
@@ -444,6 +515,18 @@ class Context(object):
         ms, n = C.c_double(), C.c_int64()
         self._ck(self._L.b7_profile_get(self._h, phase.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI (rank 0 calls it and distributes the 128 bytes)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().b7_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != B7_OK:
+        raise Bot7HipError(rc, (load().b7_last_error(None) or b"").decode())
+    return buf.raw
 
 
 def sobol_direction_numbers(dims):

@@ -3,7 +3,8 @@
     python -m bot7_amd.build [--force]
 
 One object per .hip translation unit (parallel), then one shared library next to this file.  The library
-links only against the HIP runtime (libamdhip64.so.7); no torch, no rocBLAS/rocSOLVER.
+links only against the HIP runtime (libamdhip64.so.7); no torch, no rocBLAS/rocSOLVER; librccl.so.1 is dlopen'ed
+at the first b7_comm_* call (csrc/comm.hip).
 """
 import concurrent.futures
 import os
@@ -15,12 +16,12 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libbot7hip.so")
-SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "posterior.hip", "score.hip", "extras.hip"]
+SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "posterior.hip", "score.hip", "extras.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "b7_internal.h"), os.path.join(CSRC, "gemm_f64.h"),
            os.path.join(ROOT, "include", "bot7hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-Wall",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include"]
 
 
 def _stale(target, deps):
@@ -49,7 +50,7 @@ def build(force=False, verbose=False):
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or _stale(OUT, objs):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs +
-                              ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
         if verbose:
             print("built", OUT)
     return OUT

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "b7_internal.h"
 
 static thread_local std::string g_create_err;
@@ -143,7 +145,7 @@ int b7_create(b7_ctx **out, int device_id) {
     if (g >= 1 && g <= 8) c->potrf_group = g;
   }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 8192, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 16384, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0);
   if (e != hipSuccess) {
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -165,9 +167,10 @@ void b7_destroy(b7_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)b7_comm_destroy(c);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp};
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots};
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
     for (int i = 0; i < B7_MAX_TIMERS; ++i) {
@@ -302,6 +305,41 @@ int b7_grid_remove(b7_ctx *c, int64_t idx1, double *row_out) {
   return B7_OK;
 }
 
+int b7_grid_remove_rows(b7_ctx *c, const int64_t *idx1, int64_t n, double *rows_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (n < 0 || (n > 0 && !idx1)) return b7_fail(c, B7_ERR_INVALID, "grid_remove_rows: bad index list");
+  if (n == 0) return B7_OK;
+  for (int64_t i = 0; i < n; ++i)
+    if (idx1[i] < 1 || idx1[i] > c->M)
+      return b7_fail(c, B7_ERR_INVALID, "grid_remove_rows: index %lld outside [1, %lld]", (long long)idx1[i],
+                     (long long)c->M);
+  B7_HIP(c, hipSetDevice(c->device));
+  // keep:indexFill(1, idx, 0) is idempotent: duplicates remove the row once (utils/tensor.lua:162)
+  std::vector<int64_t> idx0(idx1, idx1 + n), cuts(idx1, idx1 + n);
+  for (int64_t &v : idx0) v -= 1;
+  std::sort(cuts.begin(), cuts.end());
+  cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+  const int64_t ncut = (int64_t)cuts.size();
+  for (int64_t i = 0; i < ncut; ++i) cuts[i] = (cuts[i] - 1) - i;
+  B7_TRY(b7_ensure(c, c->tmpvar, sizeof(int64_t) * (size_t)(n + ncut)));
+  int64_t *idx0_dev = (int64_t *)c->tmpvar.p, *cuts_dev = idx0_dev + n;
+  B7_HIP(c, hipMemcpyAsync(idx0_dev, idx0.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipMemcpyAsync(cuts_dev, cuts.data(), sizeof(int64_t) * ncut, hipMemcpyHostToDevice, c->stream));
+  if (rows_out) {
+    B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * (size_t)n * c->d));
+    B7_TRY(launch_gather_rows(c, cur_grid(c), (double *)c->tmpmu.p, idx0_dev, n, c->d));
+    B7_HIP(c, hipMemcpyAsync(rows_out, c->tmpmu.p, sizeof(double) * (size_t)n * c->d, hipMemcpyDeviceToHost, c->stream));
+  }
+  const int other = c->grid_cur ^ 1;
+  B7_TRY(b7_ensure(c, c->grid[other], sizeof(double) * (size_t)c->M * c->d));
+  B7_TRY(launch_remove_rows(c, cur_grid(c), (double *)c->grid[other].p, c->M, c->d, cuts_dev, (int)ncut));
+  c->grid_cur = other;
+  c->M -= ncut;
+  invalidate_predictions(c);
+  B7_HIP(c, hipStreamSynchronize(c->stream));  // idx0 / cuts (pageable) are consumed, rows_out is complete
+  return B7_OK;
+}
+
 // ---- model ---------------------------------------------------------------------------------------------
 int b7_gp_default_opts(b7_gp_opts *o) {
   if (!o) return B7_ERR_INVALID;
@@ -328,20 +366,22 @@ static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse);
 // device result block of a fit: int info[4] | double nll_terms[1 + 256]
 static constexpr size_t B7_INFO_BYTES = 16 + sizeof(double) * 257;
 
-int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,
-              double *nll_out, double *jitter_used, int *info_out) {
-  if (!c) return B7_ERR_INVALID;
-  if (!X || !Y || !hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit: NULL argument");
-  if (N < 1 || d < 1 || ycols < 1) return b7_fail(c, B7_ERR_INVALID, "gp_fit: N %d d %d ycols %d", N, d, ycols);
-  if (d > B7_MAX_D) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: d %d > %d", d, B7_MAX_D);
-  if (ycols > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_fit: ycols %d > 256", ycols);
-  for (int k = 0; k < d; ++k)
-    if (!(hyp->lenscale_sq[k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: lenscale_sq[%d] must be > 0", k);
-  if (!(hyp->amp > 0.0) || !(hyp->noise >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: amp > 0, noise >= 0");
-  B7_HIP(c, hipSetDevice(c->device));
+// Y - mean on the device (padding rows zero): the sampler changes only the hypers, the data stay where they are
+__global__ void __launch_bounds__(256) resid_kernel(const double *__restrict__ y, double *__restrict__ r, int64_t nreal,
+                                                    int64_t ntotal, double mean) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ntotal) r[e] = e < nreal ? y[e] - mean : 0.0;
+}
 
+int b7_gp_set_data(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols) {
+  if (!c) return B7_ERR_INVALID;
+  if (!X || !Y) return b7_fail(c, B7_ERR_INVALID, "gp_set_data: NULL argument");
+  if (N < 1 || d < 1 || ycols < 1) return b7_fail(c, B7_ERR_INVALID, "gp_set_data: N %d d %d ycols %d", N, d, ycols);
+  if (d > B7_MAX_D) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_set_data: d %d > %d", d, B7_MAX_D);
+  if (ycols > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_set_data: ycols %d > 256", ycols);
+  B7_HIP(c, hipSetDevice(c->device));
   c->fitted = false;
-  c->model_kind = 0;
+  c->have_data = false;
   c->predicted = false;  // the score accumulator survives: marginalisation adds across fits (bots/bayesopt.lua:73-78)
   c->N = N;
   c->Npad = (int)round_up(N, B7_NPAD);
@@ -349,11 +389,9 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   c->dpad = b7_dpad_class(d);
   c->ycols = ycols;
   c->yld = (ycols == 1) ? 1 : (int)round_up(ycols, 64);
-  c->amp = hyp->amp;
-  c->noise = hyp->noise;
-  c->mean = hyp->mean;
   const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->xobs, sizeof(double) * np * d));  // room for b7_gp_append up to Npad rows
+  B7_TRY(b7_ensure(c, c->ybuf, sizeof(double) * np * ycols));
   B7_TRY(b7_ensure(c, c->w, sizeof(double) * c->dpad));
   B7_TRY(b7_ensure(c, c->zsc, sizeof(double) * np * c->dpad));
   B7_TRY(b7_ensure(c, c->zss, sizeof(double) * np));
@@ -365,14 +403,42 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np * c->yld));
   B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np * ycols));
   B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
-
-  // uploads (stream-ordered; the pageable source is consumed before the call returns via the sync below)
-  double *ls_dev = (double *)c->scratch.p;  // first 4096 bytes of scratch: up to 512 doubles
   B7_HIP(c, hipMemcpyAsync(c->xobs.p, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, c->stream));
-  B7_HIP(c, hipMemcpyAsync(ls_dev, hyp->lenscale_sq, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
-  std::vector<double> r(np * ycols, 0.0);
-  for (size_t i = 0; i < (size_t)N * ycols; ++i) r[i] = Y[i] - hyp->mean;
-  B7_HIP(c, hipMemcpyAsync(c->resid.p, r.data(), sizeof(double) * np * ycols, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipMemcpyAsync(c->ybuf.p, Y, sizeof(double) * (size_t)N * ycols, hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));  // the caller's arrays are consumed
+  c->have_data = true;
+  return B7_OK;
+}
+
+int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "gp_fit_hyp: call b7_gp_set_data first");
+  if (!hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit_hyp: NULL argument");
+  const int N = c->N, d = c->dfit, ycols = c->ycols;
+  for (int k = 0; k < d; ++k)
+    if (!(hyp->lenscale_sq[k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: lenscale_sq[%d] must be > 0", k);
+  if (!(hyp->amp > 0.0) || !(hyp->noise >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: amp > 0, noise >= 0");
+  B7_HIP(c, hipSetDevice(c->device));
+
+  c->fitted = false;
+  c->model_kind = 0;
+  c->predicted = false;
+  c->amp = hyp->amp;
+  c->noise = hyp->noise;
+  c->mean = hyp->mean;
+  const size_t np = (size_t)c->Npad;
+
+  // the only upload of a fit: d lengthscales, through the pinned staging slot [8192, 8960) (free again once the
+  // synchronisation that ends every fit has passed); amp / noise / mean travel as kernel arguments
+  double *ls_stage = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 8192);
+  double *ls_dev = (double *)c->scratch.p;  // first 4096 bytes of scratch: up to 512 doubles
+  memcpy(ls_stage, hyp->lenscale_sq, sizeof(double) * d);
+  B7_HIP(c, hipMemcpyAsync(ls_dev, ls_stage, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
+  {
+    const int64_t ntotal = (int64_t)np * ycols;
+    hipLaunchKernelGGL(resid_kernel, dim3((unsigned)((ntotal + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double *)c->ybuf.p, (double *)c->resid.p, (int64_t)N * ycols, ntotal, hyp->mean);
+  }
   B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
   B7_TRY(launch_kxx(c, hyp->noise));
 
@@ -414,6 +480,14 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
   return B7_OK;
 }
 
+int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,
+              double *nll_out, double *jitter_used, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit: NULL argument");
+  B7_TRY(b7_gp_set_data(c, X, Y, N, d, ycols));
+  return b7_gp_fit_hyp(c, hyp, nll_out, jitter_used, info_out);
+}
+
 }  // extern "C"
 
 static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse) {
@@ -437,16 +511,16 @@ static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, 
 // The retries of utils/math.lua:174-202 after a failed plain attempt.
 static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse) {
   const int N = c->N;
-  const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   int info = 1;
   double jitter = 0.0;
   {
-    // max_eps = src:norm() (Frobenius) of the N x N matrix that was handed to chol (:174)
-    std::vector<double> Kh((size_t)N * N);
-    B7_HIP(c, hipMemcpy2D(Kh.data(), sizeof(double) * N, c->K.p, sizeof(double) * np, sizeof(double) * N, N,
-                          hipMemcpyDeviceToHost));
+    // max_eps = src:norm() (Frobenius) of the N x N matrix that was handed to chol (:174), reduced on the device in
+    // a fixed order (it only gates the chol(I) fallback; copying K to the host cost 32 MiB of PCIe at N = 2048)
+    double *fro_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(c->info.p) + 16);
+    B7_TRY(launch_fro_norm_sq(c, (const double *)c->K.p, N, c->Npad, fro_dev));
     double fro = 0.0;
-    for (double v : Kh) fro += v * v;
+    B7_HIP(c, hipMemcpyAsync(&fro, fro_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
     const double max_eps = sqrt(fro);
     if (max_eps != max_eps)  // the reference's while-loop never ends here (eps > NaN is false); fail instead
       return b7_fail(c, B7_ERR_INVALID, "chol: the matrix contains NaN (check X_obs and the hyper-parameters)");
@@ -454,13 +528,7 @@ static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse) {
     for (;;) {
       if (eps > max_eps) {  // :184-186 chol(I)
         jitter = -1.0;
-        std::vector<double> eye(np * np, 0.0);
-        for (size_t i = 0; i < np; ++i) eye[i * np + i] = 1.0;
-        B7_HIP(c, hipMemcpy(c->L.p, eye.data(), nn, hipMemcpyHostToDevice));
-        std::vector<double> di(np * B7_PANEL, 0.0);
-        for (size_t b = 0; b < np / B7_PANEL; ++b)
-          for (int i = 0; i < B7_PANEL; ++i) di[b * B7_PANEL * B7_PANEL + i * B7_PANEL + i] = 1.0;
-        B7_HIP(c, hipMemcpy(c->dinv.p, di.data(), sizeof(double) * np * B7_PANEL, hipMemcpyHostToDevice));
+        B7_TRY(launch_set_identity(c));  // L = I, dinv = identity blocks
         c->linv_done = false;  // launch_trtri rebuilds inv(L) from this L and dinv
         break;
       }
@@ -501,6 +569,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
   if (!src || !res || n < 1) return b7_fail(c, B7_ERR_INVALID, "chol: bad arguments");
   B7_HIP(c, hipSetDevice(c->device));
   c->fitted = false;
+  c->have_data = false;
   c->predicted = false;
   c->N = n;
   c->Npad = (int)round_up(n, B7_NPAD);
@@ -638,6 +707,9 @@ int b7_gp_append(b7_ctx *c, const double *x_new, const double *y_new) {
   for (int k = 0; k < yc; ++k) r[k] = y_new[k] - c->mean;
   B7_HIP(c, hipMemcpyAsync((double *)c->resid.p + (size_t)N * yc, r.data(), sizeof(double) * yc, hipMemcpyHostToDevice,
                            c->stream));
+  if (c->have_data)  // the resident data set grows with the fit, so a later b7_gp_fit_hyp sees the new row too
+    B7_HIP(c, hipMemcpyAsync((double *)c->ybuf.p + (size_t)N * yc, y_new, sizeof(double) * yc, hipMemcpyHostToDevice,
+                             c->stream));
   double *ls_dev = (double *)c->scratch.p;  // lengthscales of the current fit
   B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N + 1, d));
   // k = K(x_new, [X; x_new]) through the covariance kernel (row 0 of a 64-row launch)
@@ -765,6 +837,7 @@ static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_
                         double *nll_out) {
   const int zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
   const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
+  c->have_data = false;
   c->N = z;
   c->Npad = zpad;
   c->ycols = 1;

@@ -44,6 +44,7 @@ struct b7_ctx {
 
   // ---- fit state
   bool fitted = false;
+  bool have_data = false;  // b7_gp_set_data has put X_obs / Y_obs on the device
   int model_kind = 0;  // 0 = GP regressor, 1 = Bayesian linear head (DNGO): selects the predict path
   int N = 0, Npad = 0, dfit = 0, dpad = 0, ycols = 0;
   int yld = 1;   // leading dimension of alpha: 1 for one column, else ycols rounded up to 64 (zero padded)
@@ -76,7 +77,9 @@ struct b7_ctx {
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
   int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
                            // Npad <= 8192, 2 always (B7_INVERSE_INLINE)
-  // 4 KiB of pinned, device-mapped host memory for the small result blocks (fit report, arg-max): kernels write
+  // 8 KiB of pinned, device-mapped host memory for the small blocks: [0, 2304) fit report, [2304, 2320) arg-max
+  // result, [4096, 6144) fmin staging, [6144, 8192) host copy of the exchange table, [8192, 8960) lengthscale
+  // staging: kernels write
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
   void *pinned_dev = nullptr;
@@ -105,6 +108,11 @@ struct b7_ctx {
   int zdim = 0;
   uint64_t feat_version = 0, grid_version = 0;
   DevBuf netbuf; // MLP weights/biases of the basis network
+
+  // ---- the arg-max exchange (comm.hip): RCCL communicator of this rank, one per context = per GPU = per process
+  void *comm = nullptr;  // ncclComm_t
+  int comm_rank = 0, comm_world = 1;
+  DevBuf slots;  // [world, 2] x u64 exchange table (also the staging of b7_comm_allreduce_f64)
 
   // ---- measurement
   hipEvent_t tev[B7_MAX_TIMERS][2];
@@ -154,6 +162,8 @@ int launch_sobol(b7_ctx *c, double *out, int64_t size, int dims, int64_t skip, c
 int launch_random_grid(b7_ctx *c, double *out, int64_t size, int dims, uint64_t seed, int64_t row_offset,
                        const double *mins, const double *maxes);
 int launch_remove_row(b7_ctx *c, const double *src, double *dst, int64_t M, int d, int64_t idx0);
+int launch_remove_rows(b7_ctx *c, const double *src, double *dst, int64_t M, int d, const int64_t *cuts_dev, int ncut);
+int launch_gather_rows(b7_ctx *c, const double *src, double *out, const int64_t *idx0_dev, int64_t n, int d);
 
 // covar.hip
 struct ObsSet {
@@ -174,6 +184,8 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I ->
 int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 int launch_nll_terms(b7_ctx *c, double *out_dev);  // out[0] = sum log L_ii, out[1 + k] = r_k' alpha_k
+int launch_fro_norm_sq(b7_ctx *c, const double *A, int n, int ld, double *out_dev);  // sum of squares of A[0:n, 0:n]
+int launch_set_identity(b7_ctx *c);    // L = I (Npad x Npad), dinv = identity blocks: the chol(I) fallback
 
 // posterior.hip
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var);
@@ -204,3 +216,5 @@ int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, i
               int ycols, double *out, bool accumulate);
 int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *best_val, int64_t *best_idx1);
 int launch_fill(b7_ctx *c, double *p, int64_t n, double v);
+int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64_t *tab_dev, int rank, int world,
+                       int64_t offset);

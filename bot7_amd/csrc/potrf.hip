@@ -1095,3 +1095,51 @@ int launch_alpha(b7_ctx *c) {
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
+
+// ---- pieces of the jitter fallback that used to run on the host ------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(1024)
+    fro_norm_sq_kernel(const double *__restrict__ A, int n, int ld, double *__restrict__ out) {
+  __shared__ double red[1024];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int64_t e = t; e < (int64_t)n * n; e += 1024) {
+    const int i = (int)(e / n), j = (int)(e - (int64_t)i * n);
+    const double v = A[(int64_t)i * ld + j];
+    s += v * v;
+  }
+  red[t] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {  // fixed tree: the same bits every time
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[0] = red[0];
+}
+__global__ void __launch_bounds__(256) set_identity_kernel(double *__restrict__ L, double *__restrict__ dinv, int n) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)n * n) {
+    const int i = (int)(e / n), j = (int)(e - (int64_t)i * n);
+    L[e] = i == j ? 1.0 : 0.0;
+  }
+  if (e < (int64_t)n * NB) {  // dinv: n/64 blocks of 64 x 64
+    const int within = (int)(e % (NB * NB));
+    dinv[e] = (within / NB == within % NB) ? 1.0 : 0.0;
+  }
+}
+}  // namespace
+
+int launch_fro_norm_sq(b7_ctx *c, const double *A, int n, int ld, double *out_dev) {
+  hipLaunchKernelGGL(fro_norm_sq_kernel, dim3(1), dim3(1024), 0, c->stream, A, n, ld, out_dev);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_set_identity(b7_ctx *c) {
+  const int n = c->Npad;
+  const int64_t total = (int64_t)n * n;
+  hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                     (double *)c->L.p, (double *)c->dinv.p, n);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}

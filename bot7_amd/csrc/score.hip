@@ -141,6 +141,22 @@ __global__ void __launch_bounds__(256) argmax_final_kernel(const Best *__restric
   if (threadIdx.x == 0) out[0] = b;
 }
 
+// The global-exchange form of argmax_final_kernel: this rank's (value bits, 1-based GLOBAL index) goes into slot
+// `rank` of the [world, 2] table of 64-bit words, every other slot is zeroed (comm.hip sums the tables of all ranks).
+__global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict__ part, int n, unsigned long long *__restrict__ tab,
+                                                          int rank, int world, long long offset) {
+  __shared__ Best sh[4];
+  Best b{0.0, -1};
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    if (better(part[j], b)) b = part[j];
+  b = block_best(b, sh);
+  for (int r = threadIdx.x; r < world; r += blockDim.x) {
+    const bool mine = r == rank && b.i >= 0;
+    tab[2 * r] = mine ? (unsigned long long)__double_as_longlong(b.v) : 0ull;
+    tab[2 * r + 1] = mine ? (unsigned long long)(offset + b.i + 1) : 0ull;
+  }
+}
+
 int nblocks(b7_ctx *c, int64_t n) {
   int64_t b = (n + 255) / 256, cap = (int64_t)c->cus * 8;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -190,5 +206,20 @@ int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *bes
   B7_HIP(c, hipStreamSynchronize(c->stream));
   if (best_val) *best_val = h.v;
   if (best_idx1) *best_idx1 = h.i + 1;
+  return B7_OK;
+}
+
+// launch_finish without the host round trip: the local result stays on the device, in this rank's slot of the
+// exchange table.  M == 0 (an empty shard) writes an all-zero table.
+int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64_t *tab_dev, int rank, int world,
+                       int64_t offset) {
+  PhaseScope ps(c, "argmax");
+  const int nb = M > 0 ? nblocks(c, M) : 0;
+  B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
+  Best *part = (Best *)c->part.p;
+  if (nb > 0) hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, c->stream, acc, M, divisor, part);
+  hipLaunchKernelGGL(argmax_slot_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb,
+                     (unsigned long long *)tab_dev, rank, world, (long long)offset);
+  B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

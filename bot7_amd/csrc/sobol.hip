@@ -169,6 +169,33 @@ __global__ void __launch_bounds__(256) remove_row_kernel(const double *__restric
     dst[e] = src[e >= cut ? e + d : e];
 }
 
+// Stable deletion of several rows at once (utils.tensor.remove takes an index tensor, utils/tensor.lua:158-170):
+// cuts[i] = (i-th smallest removed 0-based row) - i, ascending and non-decreasing; output row j comes from source
+// row j + #{i : cuts[i] <= j} (upper bound by bisection: n <= a few thousand, 11-12 steps).
+__global__ void __launch_bounds__(256) remove_rows_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                                          int64_t total_out, const int64_t *__restrict__ cuts,
+                                                          int ncut, int d) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_out; e += stride) {
+    const int64_t row = e / d;
+    int lo = 0, hi = ncut;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cuts[mid] <= row) lo = mid + 1; else hi = mid;
+    }
+    dst[e] = src[e + (int64_t)lo * d];
+  }
+}
+
+// rows_out[i][:] = src[idx0[i]][:]  (src:index(axis, idx), the rows steal appends to `pending`)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const double *__restrict__ src, double *__restrict__ out,
+                                                          const int64_t *__restrict__ idx0, int64_t total, int d) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t i = e / d;
+  out[e] = src[idx0[i] * d + (e - i * d)];
+}
+
 int grid_blocks(b7_ctx *c, int64_t total) {
   int64_t b = (total + 255) / 256;
   int64_t cap = (int64_t)c->cus * 8;
@@ -232,6 +259,27 @@ int launch_remove_row(b7_ctx *c, const double *src, double *dst, int64_t M, int 
   if (total_out > 0) {
     hipLaunchKernelGGL(remove_row_kernel, dim3(grid_blocks(c, total_out)), dim3(256), 0, c->stream, src, dst,
                        total_out, idx0 * d, d);
+    B7_HIP(c, hipGetLastError());
+  }
+  return B7_OK;
+}
+
+int launch_remove_rows(b7_ctx *c, const double *src, double *dst, int64_t M, int d, const int64_t *cuts_dev, int ncut) {
+  PhaseScope ps(c, "remove");
+  int64_t total_out = (M - ncut) * d;
+  if (total_out > 0) {
+    hipLaunchKernelGGL(remove_rows_kernel, dim3(grid_blocks(c, total_out)), dim3(256), 0, c->stream, src, dst,
+                       total_out, cuts_dev, ncut, d);
+    B7_HIP(c, hipGetLastError());
+  }
+  return B7_OK;
+}
+
+int launch_gather_rows(b7_ctx *c, const double *src, double *out, const int64_t *idx0_dev, int64_t n, int d) {
+  const int64_t total = n * d;
+  if (total > 0) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, src, out,
+                       idx0_dev, total, d);
     B7_HIP(c, hipGetLastError());
   }
   return B7_OK;

@@ -1,5 +1,6 @@
-"""Multi-GPU layout of the scoring path: one process per GPU (torch.distributed; backend "nccl" is RCCL over
-xGMI on ROCm), candidates sharded by contiguous row ranges, ONE tiny exchange per nomination.
+"""Multi-GPU layout of the scoring path: one process per GPU, candidates sharded by contiguous row ranges, ONE tiny
+exchange per nomination -- b7_score_finish_global in libbot7hip.so (csrc/comm.hip: ncclAllReduce over xGMI).  This
+module is the host-side arithmetic around it (shard ranges, the winner rule restated for the gloo rehearsal).
 
 Candidates are independent given the fitted GP (bots/bayesopt.lua:56-99 scores them elementwise and takes one
 max), so rank r of G owns rows [lo, hi) of the global grid, generates them itself (Sobol is closed-form per
@@ -79,7 +80,13 @@ class ShardedScorer(object):
         return self.ctx.grid_random(self.hi - self.lo, dims, seed, self.lo, mins, maxes, download=download)
 
     def nominate(self, divisor=1.0, device=None, group=None):
-        """score:div + global score:max(1).  Returns (value, global 1-based index)."""
+        """score:div + global score:max(1).  Returns (value, global 1-based index).
+
+        With a communicator on the context (Context.comm_init) the whole thing is ONE C-ABI call,
+        b7_score_finish_global: the product path, RCCL inside the library.  Without one, the local result is
+        exchanged through torch.distributed (the gloo rehearsal of tests/test_dist_gloo.py; same winner rule)."""
+        if self.ctx.comm_info()[1] == self.world:   # a context without a communicator reports a world of one
+            return self.ctx.score_finish_global(divisor, self.lo)
         if self.hi > self.lo:
             v, i, _ = self.ctx.score_finish(divisor, download=False)
         else:

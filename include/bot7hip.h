@@ -36,6 +36,7 @@ extern "C" {
 #define B7_ERR_STATE (-4)       /* call order: e.g. predict before fit, score before predict */
 #define B7_ERR_UNSUPPORTED (-5) /* valid in the reference, not built yet (see DESIGN.md "out of scope") */
 #define B7_ERR_RANGE (-6)       /* Sobol: dims >= 40 or index beyond 2^30-2 (grids/sobol.lua:36,317-324) */
+#define B7_ERR_COMM (-7)        /* RCCL: library not loadable, or a communicator call failed */
 
 typedef struct b7_ctx b7_ctx;
 
@@ -81,6 +82,11 @@ int b7_grid_shape(b7_ctx *ctx, int64_t *M, int *d);
  * deletion of candidate row idx1 (1-based); later rows shift up by one.  row_out (nullable, d) gets the
  * removed row (what steal appends to `pending`). */
 int b7_grid_remove(b7_ctx *ctx, int64_t idx1, double *row_out);
+/* The same for an index list, as utils.tensor.remove / steal accept (utils/tensor.lua:158-193: `idx` is a
+ * LongTensor): the rows named by idx1[0..n) (1-based, against the grid BEFORE the call; duplicates count once,
+ * keep:indexFill is idempotent) are deleted in one stable pass.  rows_out (nullable, n x d) = src:index(1, idx),
+ * in the order given. */
+int b7_grid_remove_rows(b7_ctx *ctx, const int64_t *idx1, int64_t n, double *rows_out);
 
 /* ---- model: gp_regressor + ardse + GaussianNoise_iso + constant mean (bots/bayesopt.lua:40-43) - */
 
@@ -115,6 +121,13 @@ int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
  * attempt (0 = positive definite). */
 int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp,
               double *nll_out, double *jitter_used, int *info);
+
+/* The same in two steps, for the regime Bayesian optimisation lives in: model:sample_hypers (bots/bayesopt.lua:68,
+ * 73-75) drives samplers/slice.lua:92-168, whose every density evaluation refits the SAME (X_obs, Y_obs) under new
+ * hypers.  b7_gp_set_data puts the data on the device once; b7_gp_fit_hyp then uploads d + 3 numbers per fit (the
+ * residual Y - mean is formed on the device).  b7_gp_fit == b7_gp_set_data + b7_gp_fit_hyp, bit for bit. */
+int b7_gp_set_data(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols);
+int b7_gp_fit_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info);
 
 /* utils.math.chol(src, 'L') (utils/math.lua:159-218) on a caller-provided symmetric n x n matrix: lower factor
  * with the same jitter schedule as b7_gp_fit.  res_host n x n (upper triangle zero).  Replaces the current fit
@@ -197,6 +210,34 @@ int b7_score_cb(b7_ctx *ctx, double tradeoff, int upper, double sign);
  * scores_host nullable (M). */
 int b7_score_finish(b7_ctx *ctx, double divisor, double *best_val, int64_t *best_idx1, double *scores_host);
 
+/* ---- multi-GPU: the one exchange of a candidate-sharded nomination (RCCL over xGMI) ------------ *
+ * Layout: one process per GPU, each with its own context; rank r owns candidate rows
+ * [offset_r, offset_r + M_r) of the global grid (it generates them itself: b7_grid_sobol with skip + offset_r),
+ * refits the GP redundantly, accumulates scores locally.  bots/bayesopt.lua:95-96's score:max(1) over ALL
+ * candidates is then ONE ncclAllReduce of a [world, 2] table of 64-bit words inside b7_score_finish_global.
+ * librccl is dlopen'ed at the first b7_comm_* call; a context without a communicator is a world of one. */
+#define B7_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 makes the id (no context needed) and hands the 128 bytes to the other ranks by whatever
+ * channel the host has (a file, an environment variable, a socket). */
+int b7_comm_unique_id(void *id_out);
+/* ncclCommInitRank on this context's device; collective over all `world` ranks; the exchange runs on the context's
+ * stream.  One communicator per context. */
+int b7_comm_init(b7_ctx *ctx, int rank, int world, const void *id);
+int b7_comm_info(b7_ctx *ctx, int *rank, int *world);
+int b7_comm_destroy(b7_ctx *ctx); /* also done by b7_destroy */
+/* Control-plane reduction of a few host doubles (n <= 128) over the communicator, in place; also a barrier
+ * (every rank returns only after all have entered and the context's stream has drained). */
+#define B7_COMM_SUM 0
+#define B7_COMM_MAX 1
+#define B7_COMM_MIN 2
+int b7_comm_allreduce_f64(b7_ctx *ctx, double *inout, int n, int op);
+/* b7_score_finish across ranks: score:div(divisor) on this rank's shard, local first-maximum on the device, the
+ * (value, global 1-based index = global_row_offset + local index) pairs of all ranks exchanged by one all-reduce,
+ * and on every rank the same winner by TH's rule (first NaN, else max, ties to the lowest global index): exactly
+ * what score:max(1) returns on the unsharded vector.  A rank whose shard is empty (no grid rows) still calls it. */
+int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offset, double *best_val,
+                           int64_t *best_idx1);
+
 /* EI.compute / conf_bound.compute / max on caller-provided host vectors (M x c mean, M var). */
 int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff,
                   int64_t M, int c, double *out);
@@ -213,7 +254,7 @@ int b7_timer_stop(b7_ctx *ctx, int slot);
 int b7_timer_ms(b7_ctx *ctx, int slot, float *ms_out);
 
 /* Per-kernel-phase event timing inside fit/predict/score (off by default: it serialises phases).
- * Phases: "kxx" "potrf" "trtri" "alpha" "ksx" "post" "score" "argmax" "sobol" "remove".
+ * Phases: "kxx" "potrf" "trtri" "alpha" "ksx" "post" "score" "argmax" "exchange" "sobol" "remove".
  * b7_profile_get returns the summed milliseconds and launch count since the last reset. */
 int b7_profile_enable(b7_ctx *ctx, int on);
 int b7_profile_reset(b7_ctx *ctx);

@@ -669,7 +669,7 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(ctx):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root)
-    common = ["--workload", "cfg3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    common = ["--workload", "cfg3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--candidates", "131072"]
                          + common, capture_output=True, text=True, env=env, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -820,6 +820,15 @@ def test_bench_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 1e6, "below the north-star target of 1e6 candidates/s"
+    # SURVEY 8(d) inputs: Sobol point 1 = (0.5, ..., 0.5) is an observation, so the winner is not row 1, and the
+    # GPU arg-max over the CPU leg's rows is the oracle's
+    assert d["best"]["index1"] != 1
+    bs = d["best_in_cpu_sample"]
+    assert bs["matches_cpu_argmax"] and bs["index1"] == cb["argmax1"] != 1
+    assert bs["max_abs_score_diff_vs_cpu"] < 1e-9 and bs["cpu_top2_gap"] > 10 * bs["max_abs_score_diff_vs_cpu"]
+    mg = d["marginalised"]
+    assert mg["samples"] == 10 and mg["marginalised_candidates_per_s"] > 1e5
+    assert set(d["gp_fit_ms_by_N"]) == {"256", "1024", "2048"} and all(0 < v < 50 for v in d["gp_fit_ms_by_N"].values())
     assert abs(d["value"] - d["config"]["candidates_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
 
 
@@ -926,3 +935,259 @@ def test_incremental_append_is_not_used_after_a_jittered_fit(ctx, orc):
     assert model.last_fit["jitter"] > 0.0 and model.last_fit["info"] > 0
     model.fit(X[:31], Y[:31])
     assert not model.last_fit.get("incremental") and model.last_fit["jitter"] > 0.0
+
+
+# ---- round 2: multi-index removal, resident data, the exchange behind the C ABI, full BASELINE shapes ---------------
+def test_grid_remove_rows_matches_repeated_single_removal(ctx, orc):
+    """utils.tensor.remove with an index tensor (utils/tensor.lua:158-170): one stable pass == the oracle's deletion of
+    the same rows; steal's gathered rows come back in the order given; duplicates count once."""
+    import bot7_amd
+    pool = ctx.grid_sobol(5000, 7, 1)
+    for idx in ([1], [5000], [3, 1, 4999, 77, 78, 79], list(range(1, 5000, 13)), [10, 10, 11]):
+        ctx.grid_upload(pool)
+        rows = ctx.grid_remove_rows(idx)
+        assert np.array_equal(rows, pool[np.asarray(idx) - 1])
+        want = pool
+        for i in sorted(set(idx), reverse=True):
+            want = orc.c.remove_row(want, i)
+        assert np.array_equal(ctx.grid_download(), want)
+    ctx.grid_upload(pool)
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.grid_remove_rows([0])
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.grid_remove_rows([5001])
+    assert ctx.grid_shape()[0] == 5000
+
+
+def test_set_data_fit_hyp_is_gp_fit_bit_for_bit(ctx, orc):
+    """b7_gp_set_data + b7_gp_fit_hyp == b7_gp_fit (same bits), refits under new hypers see the same data, and an
+    appended observation joins the resident data set."""
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 200, 700, B.hartmann6)
+    ctx.grid_upload(X_hid)
+    a = ctx.gp_fit(X_obs, Y, want_nll=True, **hyp)
+    La, aa, Lia = ctx.gp_download(200)
+    mu_a, var_a = ctx.gp_predict()
+    ctx.gp_set_data(X_obs, Y)
+    for scale in (1.7, 1.0):
+        h = dict(hyp, lenscale_sq=hyp["lenscale_sq"] * scale, mean=hyp["mean"] + (scale - 1.0))
+        b = ctx.gp_fit_hyp(want_nll=True, **h)
+        f = orc.gp.fit(X_obs, Y, **h)
+        assert np.allclose(b["nll"], f.nll, rtol=1e-9, atol=1e-7)
+    Lb, ab, Lib = ctx.gp_download(200)
+    mu_b, var_b = ctx.gp_predict()
+    assert a["nll"][0] == b["nll"][0] and np.array_equal(La, Lb) and np.array_equal(aa, ab) and np.array_equal(Lia, Lib)
+    assert np.array_equal(mu_a, mu_b) and np.array_equal(var_a, var_b)
+    # append, then refit from the resident data under other hypers
+    x_new, y_new = X_hid[5], B.hartmann6(X_hid[5:6])[0]
+    ctx.gp_append(x_new, y_new)
+    h2 = dict(hyp, amp=hyp["amp"] * 1.3)
+    out = ctx.gp_fit_hyp(want_nll=True, **h2)
+    f2 = orc.gp.fit(np.vstack([X_obs, x_new]), np.vstack([Y, y_new.reshape(1, -1)]), **h2)
+    assert np.allclose(out["nll"], f2.nll, rtol=1e-9, atol=1e-7)
+    import bot7_amd
+    fresh = bot7_amd.Context(0)
+    try:
+        fresh._data_d, fresh.ycols = 6, 1                 # pretend the wrapper saw data: the LIBRARY must refuse
+        with pytest.raises(bot7_amd.Bot7HipError) as e:
+            fresh.gp_fit_hyp(**hyp)
+        assert e.value.code == -4
+    finally:
+        fresh.close()
+
+
+def test_jitter_fallback_runs_on_the_device(ctx, orc):
+    """The Frobenius-norm gate and the chol(I) fallback of utils/math.lua:174-186 without a host copy of K.
+    A = -(1/n) 11' has lambda_min = -1 = -||A||_F: A + eps*I is positive definite only once eps > ||A||_F, which is
+    exactly where the schedule gives up and returns chol(I)."""
+    n = 70
+    A = -np.ones((n, n)) / n
+    L, jit, info = ctx.chol(A)
+    Lo, jit_o, _ = orc.c.chol_jitter(A)
+    assert jit == jit_o == -1.0 and info == 1 and np.array_equal(L, Lo) and np.array_equal(L, np.eye(n))
+    # and the ordinary retry path next to it: lambda_min = -1e-3, fixed by the first eps above it
+    Bm = np.eye(n) - (1.0 + 1e-3) * np.ones((n, n)) / n
+    L, jit, info = ctx.chol(Bm)
+    Lo, jit_o, _ = orc.c.chol_jitter(Bm)
+    assert jit == jit_o and jit > 1e-3 and info > 0 and np.allclose(L, Lo, rtol=1e-6, atol=1e-9)
+
+
+def test_comm_world_of_one_really_calls_rccl(orc):
+    """b7_comm_* through ctypes with world = 1: librccl gets mapped, ncclCommInitRank / ncclAllReduce really run, and
+    the global finish equals the local one with the row offset applied (ties, NaN and -0.0 included)."""
+    import bot7_amd
+    from bot7_amd import _lib
+    c = bot7_amd.Context(0)
+    try:
+        assert c.comm_info() == (0, 1)
+        uid = _lib.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        c.comm_init(0, 1, uid)
+        with open("/proc/self/maps") as f:
+            assert "librccl" in f.read()
+        assert c.comm_info() == (0, 1)
+        with pytest.raises(bot7_amd.Bot7HipError) as e:
+            c.comm_init(0, 1, uid)
+        assert e.value.code == -4
+        assert np.array_equal(c.comm_allreduce([1.5, -2.0, np.inf], "max"), [1.5, -2.0, np.inf])
+        assert np.array_equal(c.comm_allreduce([1.5, -2.0], "sum"), [1.5, -2.0])
+        X_obs, Y, X_hid, hyp = make_problem(None, orc, 6, 64, 3000, B.hartmann6)
+        off = 123456789012
+        for case in ("plain", "nan", "ties"):
+            Xh = X_hid.copy()
+            if case == "nan":
+                Xh[[700, 300]] = np.nan                  # NaN candidates -> NaN scores: the first NaN wins
+            c.gp_fit(X_obs, Y, **hyp)
+            c.grid_upload(Xh)
+            c.gp_predict(download=False)
+            c.score_reset()
+            if case != "ties":                           # "ties": the untouched accumulator, all zeros -> index 1
+                c.score_ei([float(Y.min())], 0.0)
+            v2, i2 = c.score_finish_global(1.0, off)
+            v1, i1, s = c.score_finish(1.0, download=True)
+            wi, wv = orc.c.argmax_first(s)
+            assert i1 == wi and i2 == wi + off and (v2 == wv or (v2 != v2 and wv != wv))
+            assert {"plain": wi > 1, "nan": wi == 301, "ties": wi == 1}[case]
+        c.comm_destroy()
+        assert c.comm_info() == (0, 1)
+        assert c.score_finish_global(1.0, 7)[1] == 1 + 7     # without a communicator: a world of one
+    finally:
+        c.close()
+
+
+def test_score_finish_global_matches_th_rule_on_real_scores(ctx, orc):
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 64, 3000, B.hartmann6)
+    ctx.gp_fit(X_obs, Y, **hyp)
+    ctx.grid_upload(X_hid)
+    ctx.gp_predict(download=False)
+    ctx.score_reset()
+    ctx.score_ei([float(Y.min())], 0.0)
+    ctx.score_ei([float(Y.min())], 0.0)
+    v, i = ctx.score_finish_global(2.0, 1000)
+    _, _, s = ctx.score_finish(1.0, download=True)          # already divided
+    wi, wv = orc.c.argmax_first(s)
+    assert (v, i) == (wv, wi + 1000)
+
+
+def _full_shape(ctx, orc, d, N, M, objective, sobol=True, seed_rows=7):
+    """SURVEY 8(d) inputs at a BASELINE shape, generated on the device exactly as bench.py does."""
+    import bench
+    X_obs = bench.make_inputs(ctx, d, N, M, 0, M)
+    X_hid = ctx.grid_download()
+    s = (M + N) // N
+    if sobol:   # the construction itself against the oracle's pool (strided pick + stable deletion)
+        pool = orc.c.sobol(M + N, d, 1)
+        mask = np.ones(M + N, dtype=bool)
+        mask[np.arange(N) * s] = False
+        assert np.array_equal(X_obs, pool[np.arange(N) * s]) and np.array_equal(X_hid, pool[mask])
+    Y = objective(X_obs)
+    amp = float(np.var(Y))
+    hyp = dict(lenscale_sq=np.full(d, d / 8.0), amp=amp, noise=1e-4 * amp, mean=float(np.mean(Y)))
+    return X_obs, Y, X_hid, hyp
+
+
+def test_full_shape_cfg3(ctx, orc):
+    """BASELINE config 3 at full shape: ackley d = 32, N = 1024 (Npad = 1024: 16 panels), M = 262144 Sobol
+    candidates, EI.  Oracle on a 1024-row sample + the whole-grid arg-max against TH's rule on the downloaded scores
+    + the oracle's arg-max over a 16384-row prefix."""
+    d, N, M = 32, 1024, 262144
+    X_obs, Y, X_hid, hyp = _full_shape(ctx, orc, d, N, M, B.ackley)
+    out = ctx.gp_fit(X_obs, Y, want_nll=True, **hyp)
+    f = orc.gp.fit(X_obs, Y, **hyp)
+    assert out["info"] == 0 and np.allclose(out["nll"], f.nll, rtol=1e-9)
+    mu, var = ctx.gp_predict()
+    assert (var > 0).all() and (var <= hyp["amp"] * (1 + 1e-12)).all() and np.isfinite(mu).all()
+    sample = np.random.default_rng(3).choice(M, 1024, replace=False)
+    mu_o, var_o = orc.gp.predict(f, X_hid[sample])
+    assert relerr(mu[sample], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var[sample], var_o) < REL
+    ctx.score_reset()
+    ctx.score_ei([float(Y.min())], 0.0)
+    val, idx, ei = ctx.score_finish(1.0, download=True)
+    assert (idx, val) == orc.c.argmax_first(ei) and idx != 1
+    pre = 16384
+    mu_p, var_p = orc.gp.predict(f, X_hid[:pre])
+    want = orc.c.ei(mu_p, var_p, [float(Y.min())])
+    gv, gi = ctx.argmax(ei[:pre])
+    top2 = np.partition(want, -2)[-2:]
+    print("cfg3 prefix arg-max %d, top-2 gap %.3e, max |EI - oracle| %.3e" % (gi, top2[1] - top2[0],
+                                                                           np.max(np.abs(ei[:pre] - want))))
+    assert gi == orc.c.argmax_first(want)[0]
+
+
+def test_full_shape_cfg4_per_gpu(ctx, orc):
+    """BASELINE config 4's per-GPU shape at full size: rastrigin d = 64, N = 2048, 262144 counter-based uniform
+    candidates (one of eight shards of the 2M grid), EI."""
+    import bench
+    d, N, M8, M = 64, 2048, 8 * 262144, 262144
+    X_obs = bench.make_inputs(ctx, d, N, M8, 3 * M, 4 * M)      # shard 3 of 8
+    X_hid = ctx.grid_download()
+    assert X_hid.shape == (M, d)
+    s = (M8 + N) // N
+    first = bench.pool_index(3 * M, N, s)
+    assert np.array_equal(X_hid[0], ctx_row(ctx, d, first)) and (X_obs >= 0).all() and (X_obs < 1).all()
+    ctx.grid_upload(X_hid)
+    Y = B.rastrigin(X_obs)
+    amp = float(np.var(Y))
+    hyp = dict(lenscale_sq=np.full(d, d / 8.0), amp=amp, noise=1e-4 * amp, mean=float(np.mean(Y)))
+    ctx.gp_fit(X_obs, Y, **hyp)
+    mu, var = ctx.gp_predict()
+    assert (var > 0).all() and (var <= amp * (1 + 1e-12)).all()
+    f = orc.gp.fit(X_obs, Y, **hyp)
+    sample = np.random.default_rng(4).choice(M, 512, replace=False)
+    mu_o, var_o = orc.gp.predict(f, X_hid[sample])
+    assert relerr(mu[sample], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var[sample], var_o) < REL
+    ctx.score_reset()
+    ctx.score_ei([float(Y.min())], 0.0)
+    val, idx = ctx.score_finish_global(1.0, 3 * M)
+    _, _, ei = ctx.score_finish(1.0, download=True)
+    wi, wv = orc.c.argmax_first(ei)
+    assert (val, idx) == (wv, wi + 3 * M)
+    pre = 8192
+    want = orc.c.ei(*orc.gp.predict(f, X_hid[:pre]), [float(Y.min())])
+    assert ctx.argmax(ei[:pre])[1] == orc.c.argmax_first(want)[0]
+
+
+def ctx_row(ctx, d, pool_row):
+    """One row of the counter-based uniform pool (seed 1), regenerated on a scratch context."""
+    import bot7_amd
+    c = bot7_amd.Context(0)
+    try:
+        return c.grid_random(1, d, seed=1, row_offset=pool_row)[0]
+    finally:
+        c.close()
+
+
+def test_full_shape_cfg5(ctx, orc):
+    """BASELINE config 5 at full shape: DNGO head (3 x 50 tanh basis) over 65536 Sobol candidates, N = 256, with
+    responses that are linear in the features (EI of order 1e-1 at the winners, not an underflow): the Bayesian linear
+    head against oracle/blr.py on a 512-row sample, and the arg-max over the whole grid against the oracle."""
+    from oracle import blr
+    import bench
+    d, N, M = 5, 256, 65536
+    X_obs = bench.make_inputs(ctx, d, N, M, 0, M)
+    X_hid = ctx.grid_download()
+    rng = np.random.default_rng(0)
+    dims = [d, 50, 50, 50]
+    W = [rng.normal(scale=1.0 / np.sqrt(dims[i]), size=(dims[i + 1], dims[i])) for i in range(3)]
+    b = [rng.normal(scale=0.1, size=dims[i + 1]) for i in range(3)]
+    Z0 = ctx.blr_basis(W, b, "Tanh", X=X_obs)
+    Y = Z0 @ rng.normal(size=(50, 1)) + 0.1 * rng.normal(size=(N, 1))
+    alpha_p, beta, ymean = 1.0, 100.0, float(np.mean(Y))
+    nll = ctx.blr_fit_x(W, b, "Tanh", X_obs, Y, alpha_p, beta, ymean, want_nll=True)
+    f = blr.fit(blr.basis(X_obs, W, b, "Tanh"), Y, alpha_p, beta, ymean)
+    assert nll == pytest.approx(float(f["nll"]), rel=1e-9, abs=1e-7)
+    ctx.blr_basis(W, b, "Tanh")
+    mu, var = ctx.blr_predict()
+    sample = np.random.default_rng(1).choice(M, 512, replace=False)
+    mu_o, var_o = blr.predict(f, blr.basis(X_hid[sample], W, b, "Tanh"))
+    assert relerr(mu[sample], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var[sample], var_o) < REL
+    ctx.score_reset()
+    ctx.score_ei([float(Y.min())], 0.0)
+    val, idx, ei = ctx.score_finish(1.0, download=True)
+    mu_all, var_all = blr.predict(f, blr.basis(X_hid, W, b, "Tanh"))
+    want = orc.c.ei(mu_all, var_all, [float(Y.min())])
+    wi, wv = orc.c.argmax_first(want)
+    top2 = np.partition(want, -2)[-2:]
+    print("cfg5 EI max %.4g (index %d), top-2 gap %.3e, max |EI - oracle| %.3e" % (wv, wi, top2[1] - top2[0],
+                                                                                 np.max(np.abs(ei - want))))
+    assert wv > 1e-3, "EI at the winner should be O(1e-2 .. 1), not an underflow"
+    assert idx == wi and val == pytest.approx(wv, rel=1e-6)
