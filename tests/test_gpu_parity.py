@@ -1075,7 +1075,7 @@ def _full_shape(ctx, orc, d, N, M, objective, sobol=True, seed_rows=7):
     X_hid = ctx.grid_download()
     s = (M + N) // N
     if sobol:   # the construction itself against the oracle's pool (strided pick + stable deletion)
-        pool = orc.c.sobol(M + N, d, 1)
+        pool = orc.c.sobol(M + N, d, bench.SOBOL_SKIP)
         mask = np.ones(M + N, dtype=bool)
         mask[np.arange(N) * s] = False
         assert np.array_equal(X_obs, pool[np.arange(N) * s]) and np.array_equal(X_hid, pool[mask])
