@@ -995,20 +995,17 @@ def test_set_data_fit_hyp_is_gp_fit_bit_for_bit(ctx, orc):
         fresh.close()
 
 
-def test_jitter_fallback_runs_on_the_device(ctx, orc):
-    """The Frobenius-norm gate and the chol(I) fallback of utils/math.lua:174-186 without a host copy of K.
-    A = -(1/n) 11' has lambda_min = -1 = -||A||_F: A + eps*I is positive definite only once eps > ||A||_F, which is
-    exactly where the schedule gives up and returns chol(I)."""
+def test_jitter_schedule_gate_is_computed_on_the_device(ctx, orc):
+    """The Frobenius-norm gate of utils/math.lua:174 comes from a device reduction now (no host copy of K).  The
+    chol(I) branch behind it (:184-186) cannot be reached with finite input -- a failed attempt needs eps <= -lambda_min
+    <= ||A||_F, the branch needs eps > ||A||_F -- so what is checked is the retry path right up to the gate:
+    A = -(1/n) 11' has lambda_min = -1 = -||A||_F and is fixed by the first eps above 1."""
     n = 70
-    A = -np.ones((n, n)) / n
-    L, jit, info = ctx.chol(A)
-    Lo, jit_o, _ = orc.c.chol_jitter(A)
-    assert jit == jit_o == -1.0 and info == 1 and np.array_equal(L, Lo) and np.array_equal(L, np.eye(n))
-    # and the ordinary retry path next to it: lambda_min = -1e-3, fixed by the first eps above it
-    Bm = np.eye(n) - (1.0 + 1e-3) * np.ones((n, n)) / n
-    L, jit, info = ctx.chol(Bm)
-    Lo, jit_o, _ = orc.c.chol_jitter(Bm)
-    assert jit == jit_o and jit > 1e-3 and info > 0 and np.allclose(L, Lo, rtol=1e-6, atol=1e-9)
+    for A in (-np.ones((n, n)) / n, np.eye(n) - (1.0 + 1e-3) * np.ones((n, n)) / n):
+        L, jit, info = ctx.chol(A)
+        Lo, jit_o, _ = orc.c.chol_jitter(A)
+        assert jit == jit_o and jit > 0 and info > 0 and np.allclose(L, Lo, rtol=1e-6, atol=1e-9)
+    assert ctx.chol(-np.ones((n, n)) / n)[1] == pytest.approx(1e-8 * 1.1 ** 194, rel=1e-12)
 
 
 def test_comm_world_of_one_really_calls_rccl(orc):
