@@ -1,0 +1,38 @@
+--[[
+Drop-in for bot7.grids.random (grids/random.lua:23-35) backed by b7_grid_random.
+Register:  bot7.grids.random_hip = require('bot7hip.grids_random_hip')   (config.grid.type = 'random_hip')
+torch.rand's MT19937 stream is not part of the reference tree, so the uniforms come from the library's counter-based
+generator (config.seed, default 0; a rank that owns rows [lo, hi) of a global grid passes config.row_offset = lo);
+the affine map and its one-sided branches are the reference's (:27-33).  The grid stays resident on the GPU.
+--]]
+local ffi = require('ffi')
+local hip = require('bot7hip.bot7hip_ffi')
+
+local title  = 'bot7.grids.random_hip'
+local parent = 'bot7.grids.abstract'
+local grid, parent = torch.class(title, parent)
+
+function grid:__init(config)
+  parent.__init(self)
+  self.config = config or {}
+end
+
+function grid:generate(config)
+  local config = config or self.config
+  local out    = torch.DoubleTensor(config.size, config.dims)
+  local both   = config.mins and config.maxes
+  local mins, maxes = both and hip.pin(config.mins) or nil, both and hip.pin(config.maxes) or nil
+  hip.check(hip.C.b7_grid_random(hip.ctx, config.size, config.dims, config.seed or 0, config.row_offset or 0,
+                                 hip.data(mins), hip.data(maxes), torch.data(out)))            -- :24, :27-28
+  if not both and config.mins then          -- :29-30
+    out:add(torch.add(config.mins, out:min(1)[1]):expandAs(out))
+    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
+  elseif not both and config.maxes then     -- :31-32
+    out:cmul(torch.cdiv(config.maxes, out:max(1)[1]):expandAs(out))
+    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
+  end
+  hip.set_resident(out)
+  return out
+end
+
+return grid

@@ -23,12 +23,11 @@ end
 
 function grid:generate(config)
   local config = config or self.config
-  local skip   = config.skip or 1
+  local skip   = config.skip or 1                 -- :70 (0 is truthy in Lua: skip = 0 stays 0)
   local out    = torch.DoubleTensor(config.size, config.dims)
   local both   = config.mins and config.maxes
-  hip.check(hip.C.b7_grid_sobol(hip.ctx, config.size, config.dims, skip,
-            both and hip.ptr(config.mins) or nil, both and hip.ptr(config.maxes) or nil, torch.data(out)))
-  hip.grid_version = hip.grid_version + 1
+  local mins, maxes = both and hip.pin(config.mins) or nil, both and hip.pin(config.maxes) or nil
+  hip.check(hip.C.b7_grid_sobol(hip.ctx, config.size, config.dims, skip, hip.data(mins), hip.data(maxes), torch.data(out)))
   if not both and config.mins then          -- grids/sobol.lua:82-83 (host side, rare)
     out:add(torch.add(config.mins, out:min(1)[1]):expandAs(out))
     hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
@@ -36,7 +35,7 @@ function grid:generate(config)
     out:cmul(torch.cdiv(config.maxes, out:max(1)[1]):expandAs(out))
     hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
   end
-  hip.resident = {ptr = torch.data(out), rows = out:size(1), version = hip.grid_version}
+  hip.set_resident(out)
   return out
 end
 

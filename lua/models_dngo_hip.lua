@@ -47,10 +47,9 @@ function dngo:predict(X0, Y0, X1, hyp, req, skip)
   local z  = keep[3][#keep[1]]
   local h  = self.blr_hyp or {alpha = 1.0, beta = 1.0 / (1e-2 * Y0:var()), mean = Y0:mean()}
   -- :155-162 (features of X0) and the fit half of :174 in one call; Z0 never leaves the device
-  hip.check(hip.C.b7_blr_fit_x(hip.ctx, net, hip.ptr(X0), hip.ptr(Y0), X0:size(1), h.alpha, h.beta, h.mean, nil))
-  local X = X1:contiguous()
-  hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(X), X:size(1), X:size(2)))
-  hip.grid_version = hip.grid_version + 1
+  local X0c, Y0c = hip.pin(X0), hip.pin(Y0)
+  hip.check(hip.C.b7_blr_fit_x(hip.ctx, net, hip.data(X0c), hip.data(Y0c), X0:size(1), h.alpha, h.beta, h.mean, nil))
+  if not hip.is_resident(X1) then hip.upload_grid(X1) end
   hip.check(hip.C.b7_blr_basis(hip.ctx, net, nil, 0, nil))                                        -- :164-171
   local mean, var = torch.DoubleTensor(X1:size(1), 1), torch.DoubleTensor(X1:size(1))
   hip.check(hip.C.b7_blr_predict(hip.ctx, torch.data(mean), torch.data(var)))                     -- :174

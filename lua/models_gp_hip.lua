@@ -1,9 +1,18 @@
 --[[
 Drop-in for gp.models.gp_regressor (ardse + GaussianNoise_iso + constant mean, bots/bayesopt.lua:39-45)
-backed by b7_gp_fit / b7_gp_predict.  Register:  bot7.models.gp_hip = require('bot7hip.models_gp_hip')
+backed by b7_gp_set_data / b7_gp_fit_hyp / b7_gp_predict.
+Register:  bot7.models.gp_hip = require('bot7hip.models_gp_hip')
 and select it with config.model.type = 'gp_hip' (bots/bayesopt.lua:31), or pass it as cache.model.
+Mirrors bot7_amd/models/gp_regressor.py method for method (that file is what the tests drive).
 
-Hyper vector layout (ours): { lenscale_sq_1..d, amp, noise, mean }.
+Hyper vector layout (ours; the gp rock's parse_hypers layout is not in the reference tree):
+    { lenscale_sq_1..d, amp, noise, mean }
+Hyper sampling (config.sampler = 'slice', bots/bayesopt.lua:44): with config.sample = true the reference's OWN
+bot7.samplers.slice (samplers/slice.lua:51-168) walks
+    log p(theta | X, Y) = -NLL(theta) + log prior(theta),   theta = { log lenscale_sq, log amp, log noise, mean }
+with a flat prior inside explicit bounds (config.bounds; the gp rock's priors are unknown); every density evaluation
+is one b7_gp_fit_hyp (d + 3 numbers uploaded, the data stay on the device).  config.sample = false (default):
+sample_hypers returns the current point estimate.
 --]]
 local ffi = require('ffi')
 local hip = require('bot7hip.bot7hip_ffi')
@@ -15,20 +24,108 @@ local model, parent = torch.class(title, parent)
 function model:__init(config)
   parent.__init(self)
   self.config = config or {}
-  self.hyp = nil
+  self.hyp    = nil
+  self.nEvals = 0
 end
 
 function model:init(X_obs, Y_obs)                       -- bots/abstract.lua:147-149
-  local d   = X_obs:size(2)
-  local amp = (Y_obs:size(1) > 1) and Y_obs:var() * (Y_obs:size(1) - 1) / Y_obs:size(1) or 1.0
+  local d, n = X_obs:size(2), Y_obs:size(1)
+  local amp  = (n > 1) and Y_obs:var() * (n - 1) / n or 1.0       -- population variance, as numpy.var
   if not (amp > 0) then amp = 1.0 end
   self.hyp = {lenscale_sq = torch.DoubleTensor(d):fill(d / 8), amp = amp,
               noise = self.config.noiseless and 0.0 or 1e-4 * amp, mean = Y_obs:mean()}
   return self.hyp
 end
 
-function model:sample_hypers(X_obs, Y_obs, _, _, state) -- bots/bayesopt.lua:68,74 (point estimate; slice sampling
-  if not self.hyp then self:init(X_obs, Y_obs) end      -- over model:nll is the 8f-1 'next' row)
+-- ---- theta <-> hyp, bounds -------------------------------------------------------------------------------------------
+local function to_theta(h)
+  local d = h.lenscale_sq:nElement()
+  local t = torch.DoubleTensor(d + 3)
+  t:narrow(1, 1, d):copy(h.lenscale_sq):log()
+  t[d+1] = math.log(h.amp); t[d+2] = math.log(math.max(h.noise, 1e-300)); t[d+3] = h.mean
+  return t
+end
+local function from_theta(t)
+  local d = t:nElement() - 3
+  return {lenscale_sq = t:narrow(1, 1, d):clone():exp(), amp = math.exp(t[d+1]), noise = math.exp(t[d+2]), mean = t[d+3]}
+end
+function model:bounds(X, Y)
+  local b, d = self.config.bounds or {}, X:size(2)
+  local n  = Y:size(1)
+  local vy = (n > 1) and Y:var() * (n - 1) / n or 1.0
+  if not (vy > 0) then vy = 1.0 end
+  local lo, hi = torch.DoubleTensor(d + 3), torch.DoubleTensor(d + 3)
+  lo:narrow(1, 1, d):fill(math.log(b.lenscale_sq_min or 1e-3 * d)); hi:narrow(1, 1, d):fill(math.log(b.lenscale_sq_max or 1e3 * d))
+  lo[d+1] = math.log(b.amp_min   or 1e-3 * vy); hi[d+1] = math.log(b.amp_max   or 1e3 * vy)
+  lo[d+2] = math.log(b.noise_min or 1e-8 * vy); hi[d+2] = math.log(b.noise_max or 1e0 * vy)
+  lo[d+3] = b.mean_min or (Y:min() - 3 * math.sqrt(vy)); hi[d+3] = b.mean_max or (Y:max() + 3 * math.sqrt(vy))
+  return lo, hi
+end
+
+-- ---- fits ---------------------------------------------------------------------------------------------------------------
+-- The data go to the device once per (X_obs, Y_obs) pair: the sampler and the marginalisation loop refit the SAME
+-- tensors under new hypers (bots/bayesopt.lua:68-78), so a pointer + shape match means "already resident".
+local function same_data(self, X, Y)
+  local k = self._data
+  return k ~= nil and k.xp == torch.data(X) and k.yp == torch.data(Y) and k.n == X:size(1) and k.d == X:size(2)
+         and k.c == Y:size(2) and k.xs == X:sum() and k.ys == Y:sum()   -- an allocator may hand the address out again
+end
+
+function model:fit(X_obs, Y_obs, hyp, want_nll)
+  local hyp = hyp or self.hyp
+  local X = hip.pin(X_obs)
+  local Y = hip.pin(Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs)
+  if not (same_data(self, X, Y) and X_obs:isContiguous() and Y_obs:isContiguous()) then
+    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))
+    self._data = {xp = torch.data(X), yp = torch.data(Y), n = X:size(1), d = X:size(2), c = Y:size(2),
+                  xs = X:sum(), ys = Y:sum()}
+  end
+  local ls = hip.pin(hyp.lenscale_sq)
+  local h  = ffi.new('b7_hyp', {hip.data(ls), hyp.amp, hyp.noise, hyp.mean})
+  local nll, jit, info = ffi.new('double[?]', Y:size(2)), ffi.new('double[1]'), ffi.new('int[1]')
+  hip.check(hip.C.b7_gp_fit_hyp(hip.ctx, h, want_nll and nll or nil, jit, info))
+  if jit[0] > 0 then   -- the reference's warning text, utils/math.lua:210-212
+    print(string.format('Warning: utils.math.chol succeeded in factorizing the\ninput matrix after applying a jitter of %.2e', jit[0]))
+  elseif jit[0] < 0 then   -- :185-186
+    print('Warning: utils.math.chol failed to factorize the input matrix; returning chol(I)')
+  end
+  self.last_fit = {jitter = jit[0], info = info[0]}
+  return nll[0]
+end
+
+function model:nll(X_obs, Y_obs, hyp) return self:fit(X_obs, Y_obs, hyp or self.hyp, true) end
+
+-- -NLL on the device + flat prior inside the bounds (-inf outside): the density bot7.samplers.slice evaluates
+function model:log_posterior(theta, X_obs, Y_obs)
+  local theta = theta:view(-1)
+  local lo, hi = self:bounds(X_obs, Y_obs)
+  if theta:lt(lo):any() or theta:gt(hi):any() or theta:ne(theta):any() then return -math.huge end
+  self.nEvals = self.nEvals + 1
+  return -self:nll(X_obs, Y_obs, from_theta(theta))
+end
+
+function model:sample_hypers(X_obs, Y_obs, _, _, state) -- bots/bayesopt.lua:68 (burn-in) and :74 (state = true)
+  if not self.hyp then self:init(X_obs, Y_obs) end
+  if self.config.sample then
+    local Samplers = require('bot7.samplers')
+    if not self.sampler then
+      self.sampler = Samplers[self.config.sampler or 'slice']()          -- bots/bayesopt.lua:44
+      self.sopt    = self.sampler.configure(self.config.sampler_opt or {})  -- samplers/slice.lua:32-48
+      self.sopt.width = self.sopt.width or 0.5
+    end
+    if self.config.noiseless and not (self.hyp.noise > 0) then
+      local lo = self:bounds(X_obs, Y_obs)
+      self.hyp.noise = math.exp(lo[X_obs:size(2) + 2])
+    end
+    local theta     = to_theta(self.hyp)
+    local n_updates = state and 1 or (self.config.nBurnin or 0)
+    local f = function(t, _) return self:log_posterior(t, X_obs, Y_obs) end
+    self.sopt.nSamples = 1
+    for _ = 1, n_updates do
+      theta = self.sampler.sample(f, theta:view(1, -1), self.sopt, nil)[1]  -- samplers/slice.lua:51-89
+    end
+    self.hyp = from_theta(theta)
+  end
   local h = self.hyp
   return torch.cat(h.lenscale_sq, torch.DoubleTensor{h.amp, h.noise, h.mean})
 end
@@ -38,56 +135,36 @@ function model:parse_hypers(v)                          -- bots/bayesopt.lua:75
   return {lenscale_sq = v:narrow(1, 1, d):clone(), amp = v[d+1], noise = v[d+2], mean = v[d+3]}
 end
 
-local function fit(X_obs, Y_obs, hyp, want_nll)
-  local h = ffi.new('b7_hyp', {hip.ptr(hyp.lenscale_sq), hyp.amp, hyp.noise, hyp.mean})
-  local nll, jit, info = ffi.new('double[1]'), ffi.new('double[1]'), ffi.new('int[1]')
-  local Y = Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs
-  hip.check(hip.C.b7_gp_fit(hip.ctx, hip.ptr(X_obs), hip.ptr(Y), X_obs:size(1), X_obs:size(2), Y:size(2), h,
-                            want_nll and nll or nil, jit, info))
-  if jit[0] > 0 then   -- the reference's warning text, utils/math.lua:210-212
-    print(string.format('Warning: utils.math.chol succeeded in factorizing the\ninput matrix after applying a jitter of %.2e', jit[0]))
-  end
-  return nll[0]
-end
-
-function model:nll(X_obs, Y_obs, hyp) return fit(X_obs, Y_obs, hyp or self.hyp, true) end
-
-local function is_resident(X1)
-  local r = hip.resident
-  return r and r.version == hip.grid_version and r.rows == X1:size(1) and r.ptr == torch.data(X1)
-end
-
+-- ---- posterior ----------------------------------------------------------------------------------------------------------
 -- fit + predict leaving mean/var on the device (used by the *_hip scores)
 function model:predict_device(X_obs, Y_obs, X_hid, hyp)
-  fit(X_obs, Y_obs, hyp or self.hyp, false)
-  if not is_resident(X_hid) then
-    local X = X_hid:contiguous()
-    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(X), X:size(1), X:size(2)))
-    hip.grid_version = hip.grid_version + 1
-    hip.resident = {ptr = torch.data(X_hid), rows = X_hid:size(1), version = hip.grid_version}
-  end
+  self:fit(X_obs, Y_obs, hyp or self.hyp, false)
+  if not hip.is_resident(X_hid) then hip.upload_grid(X_hid) end
   hip.check(hip.C.b7_gp_predict(hip.ctx, nil, nil))
 end
 
 function model:predict(X_obs, Y_obs, X_hid, hyp, req)   -- scores/expected_improvement.lua:63
   local req  = req or {mean = true, var = true}
   local M    = X_hid:size(1)
-  local mean, var = torch.DoubleTensor(M, 1), torch.DoubleTensor(M)
-  fit(X_obs, Y_obs, hyp or self.hyp, false)
-  if is_resident(X_hid) then
+  local c    = (Y_obs:dim() == 1) and 1 or Y_obs:size(2)
+  local mean, var = torch.DoubleTensor(M, c), torch.DoubleTensor(M)
+  self:fit(X_obs, Y_obs, hyp or self.hyp, false)
+  if hip.is_resident(X_hid) then
     hip.check(hip.C.b7_gp_predict(hip.ctx, torch.data(mean), torch.data(var)))
   else
-    hip.check(hip.C.b7_gp_predict_at(hip.ctx, hip.ptr(X_hid), M, torch.data(mean), torch.data(var)))
+    local X = hip.pin(X_hid)
+    hip.check(hip.C.b7_gp_predict_at(hip.ctx, hip.data(X), M, torch.data(mean), torch.data(var)))
   end
   return {mean = req.mean and mean or nil, var = req.var and var or nil}
 end
 
 function model:fantasize(nFantasies, X_obs, Y_obs, X_pend, hyp)   -- scores/expected_improvement.lua:57
-  fit(X_obs, Y_obs, hyp or self.hyp, false)
+  self:fit(X_obs, Y_obs, hyp or self.hyp, false)
   self.fcalls = (self.fcalls or 0) + 1
-  local P   = X_pend:size(1)
+  local Xp  = hip.pin(X_pend)
+  local P   = Xp:size(1)
   local out = torch.DoubleTensor(P, nFantasies)
-  hip.check(hip.C.b7_gp_fantasize(hip.ctx, hip.ptr(X_pend), P, nFantasies, (self.config.seed or 0) * 1000003 + self.fcalls,
+  hip.check(hip.C.b7_gp_fantasize(hip.ctx, hip.data(Xp), P, nFantasies, (self.config.seed or 0) * 1000003 + self.fcalls,
                                   torch.data(out), nil, nil))
   return out
 end

@@ -1,0 +1,118 @@
+"""The Lua shims cannot run in this pipeline (no LuaJIT / Torch7), so they are checked statically against the header
+they bind: the cdef block is the header, every hip.C.b7_*(...) call names a declared function with the declared
+number of arguments, the constants match the #defines, and the shims cover the protocol the driver speaks."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_lua_cdef  # noqa: E402
+
+LUA = os.path.join(ROOT, "lua")
+HEADER = open(os.path.join(ROOT, "include", "bot7hip.h")).read()
+
+
+def lua_files():
+    return sorted(f for f in os.listdir(LUA) if f.endswith(".lua"))
+
+
+def strip_lua_comments(src):
+    src = re.sub(r"--\[\[.*?\]\]", "", src, flags=re.S)
+    return re.sub(r"--[^\n]*", "", src)
+
+
+def prototypes():
+    """name -> number of parameters, from the header's declarations."""
+    out = {}
+    for d in gen_lua_cdef.cdef_lines(HEADER):
+        m = re.match(r"^(?!typedef).*?\b(b7_[a-z0-9_]+)\s*\((.*)\)\s*;$", d)
+        if m:
+            args = m.group(2).strip()
+            out[m.group(1)] = 0 if args in ("", "void") else len(split_args(args))
+    return out
+
+
+def split_args(s):
+    parts, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    return [p for p in (q.strip() for q in parts)]
+
+
+def calls(src):
+    """(name, nargs) of every hip.C.b7_x(...) / C.b7_x(...) call, arguments split at top-level commas."""
+    out = []
+    for m in re.finditer(r"\bC\.(b7_[a-z0-9_]+)\s*\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            ch = src[i]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            i += 1
+        inner = src[m.end():i - 1].strip()
+        out.append((m.group(1), 0 if inner == "" else len(split_args(inner))))
+    return out
+
+
+def test_cdef_block_is_the_header():
+    src = open(os.path.join(LUA, "bot7hip_ffi.lua")).read()
+    block = src.split("-- BEGIN generated from include/bot7hip.h (tools/gen_lua_cdef.py)\n")[1].split("-- END generated")[0]
+    assert block.strip().splitlines() == gen_lua_cdef.cdef_lines(HEADER), \
+        "lua/bot7hip_ffi.lua is out of date: regenerate the cdef block with tools/gen_lua_cdef.py"
+    consts = src.split("-- BEGIN generated constants\n")[1].split("-- END generated constants")[0]
+    want = ["M.%s = %d" % (k[3:], v) for k, v in gen_lua_cdef.defines(HEADER).items()]
+    assert consts.strip().splitlines() == want
+
+
+def test_every_ffi_call_matches_a_declared_prototype():
+    protos = prototypes()
+    assert len(protos) >= 50
+    seen = set()
+    for f in lua_files():
+        src = strip_lua_comments(open(os.path.join(LUA, f)).read())
+        if f == "bot7hip_ffi.lua":
+            src = src.split("-- END generated")[-1] if "-- END generated" in src else src
+            src = re.sub(r"ffi\.cdef\[\[.*?\]\]", "", open(os.path.join(LUA, f)).read(), flags=re.S)
+            src = strip_lua_comments(src)
+        for name, nargs in calls(src):
+            assert name in protos, "%s calls %s, which include/bot7hip.h does not declare" % (f, name)
+            assert nargs == protos[name], "%s calls %s with %d arguments, the header declares %d" % (
+                f, name, nargs, protos[name])
+            seen.add(name)
+    # the entry points the driver's protocol needs are all reached from some shim
+    for must in ("b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_remove_rows", "b7_gp_set_data",
+                 "b7_gp_fit_hyp", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_score_reset", "b7_score_ei",
+                 "b7_score_cb", "b7_score_finish", "b7_score_finish_global", "b7_comm_unique_id", "b7_comm_init",
+                 "b7_blr_fit_x", "b7_blr_basis", "b7_blr_predict"):
+        assert must in seen, "no Lua shim calls %s" % must
+
+
+def test_shims_speak_the_driver_protocol():
+    """Method names the reference's driver calls on its plug-ins exist in the shim classes, and the
+    pending-points branch of EI does what scores/expected_improvement.lua:51-60 does."""
+    gp = strip_lua_comments(open(os.path.join(LUA, "models_gp_hip.lua")).read())
+    for meth in ("init", "sample_hypers", "parse_hypers", "predict", "fantasize", "nll", "predict_device"):
+        assert re.search(r"function model:%s\(" % meth, gp), meth
+    assert "bot7.samplers" in gp and "self.sampler.sample(" in gp and "log_posterior" in gp   # samplers/slice.lua drives nll
+    sc = strip_lua_comments(open(os.path.join(LUA, "scores_hip.lua")).read())
+    assert re.search(r"model:fantasize\(config\.nFantasies,\s*X_obs,\s*Y_obs,\s*X_pend,\s*hyp\)", sc)
+    assert "X_obs:cat(X_pend, 1)" in sc and "repeatTensor(1, config.nFantasies):cat(Y_pend, 1)" in sc
+    ffi = strip_lua_comments(open(os.path.join(LUA, "bot7hip_ffi.lua")).read())
+    assert "install_steal_hook" in ffi and "b7_grid_remove_rows" in ffi and "T.steal = function" in ffi
+    for f in ("grids_sobol_hip.lua", "grids_random_hip.lua"):
+        g = strip_lua_comments(open(os.path.join(LUA, f)).read())
+        assert "function grid:generate(config)" in g and "hip.set_resident(out)" in g
+    # no shim takes a pointer from a temporary: torch.data(x:contiguous()) is the pattern ADVICE r1 flagged
+    for f in lua_files():
+        assert "torch.data(" + "t:contiguous())" not in open(os.path.join(LUA, f)).read(), f
+        assert not re.search(r"torch\.data\(\s*[A-Za-z_0-9.]+:contiguous\(\)\s*\)", open(os.path.join(LUA, f)).read()), f

@@ -1,0 +1,39 @@
+"""The ffi.cdef body of lua/bot7hip_ffi.lua IS include/bot7hip.h: this prints the header with comments, the include
+guard, #include / #define lines and the extern "C" wrapper stripped, one declaration per line.
+tests/test_abi_and_host.py compares its output with the block in the .lua file.   usage: gen_lua_cdef.py [header]"""
+import os
+import re
+import sys
+
+
+def cdef_lines(header_text):
+    t = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)           # comments
+    t = re.sub(r"^\s*#.*$", "", t, flags=re.M)                        # preprocessor lines
+    t = re.sub(r'extern\s+"C"\s*\{', "", t)
+    t = re.sub(r"^\s*\}\s*$", "", t, flags=re.M)                      # the closing brace of extern "C"
+    decls, cur, depth = [], "", 0
+    for ch in t:
+        cur += ch
+        depth += ch == "{"
+        depth -= ch == "}"
+        if ch == ";" and depth == 0:
+            decls.append(re.sub(r"\s+", " ", cur).strip())
+            cur = ""
+    return [d for d in decls if d]
+
+
+def defines(header_text):
+    out = {}
+    for name, val in re.findall(r"^\s*#define\s+(B7_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", header_text, flags=re.M):
+        out[name] = int(val)
+    return out
+
+
+if __name__ == "__main__":
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                              "include", "bot7hip.h")
+    text = open(path).read()
+    print("\n".join(cdef_lines(text)))
+    print("-- constants")
+    for k, v in defines(text).items():
+        print("M.%s = %d" % (k[3:], v))
