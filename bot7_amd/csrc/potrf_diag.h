@@ -1,0 +1,320 @@
+// The serial heart of the Cholesky: factor AND invert one 64x64 diagonal block that sits in LDS.  Shared by the
+// per-panel launch schedule (potrf.hip: potrf_diag_kernel) and the persistent schedule (potrf_persist.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "gemm_f64.h"
+
+namespace b7diag {
+
+constexpr int NB = 64;
+
+// ---- 64x64 diagonal block: factor and invert, blocked by 16 -----------------------------------------------------
+// The serial part of the whole Cholesky.  Per 16-wide sub-block kb, wave 0 factors the 16x16 diagonal sub-block with
+// one matrix row per lane (16 registers), pivots and multipliers broadcast through DPP (no LDS, no barriers); the
+// same instruction stream inverts it (lane row 0) and solves the sub-panel rows below it (lane rows 1..3).  The
+// trailing update inside the 64x64 block and the assembly of the 64x64 inverse from the four 16x16 inverses (two
+// doubling levels, X = -inv(C) * (B * inv(A))) are 16x16x16 MFMA products; VAR 1 runs as many of them as the data
+// dependences allow on waves 1..3 while wave 0 is already in the next factor step.  The f64 accumulator layout
+// (row = (l>>4)+4r) is exactly the B-operand layout of k-step r, so T = B*inv(A) feeds the second product of a
+// doubling level straight from registers.
+constexpr int DLD = NB + 2;  // LDS row stride: = 2 (mod 4) doubles -> conflict-free ds_read_b64 fragments
+constexpr int TLD = 34;
+
+template <int J>
+__device__ __forceinline__ double row_share(double v) {  // value of lane J of this lane's 16-lane row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + J, 0xF, 0xF, true);  // every lane of the row is a valid source
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// 64-bit row broadcast as ONE instruction (v_mov_b64_dpp row_newbcast: the only DPP control the fp64 ALU has)
+template <int J>
+__device__ __forceinline__ double row_share64(double v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, false);
+}
+// acc += (value of `src` in lane J of this lane's 16-lane row) * mul, as ONE instruction: v_fmac_f64 with its first
+// operand taken through DPP (5 cycles of issue; mov_dpp + fma is 8 + 5, the old 32-bit pair 16 + 5 --
+// tools/valu_probe.hip).  hipcc does not form it from mov_dpp + fma, hence the asm.  A DPP read needs two wait
+// states after a VALU write of the same register and the compiler cannot see into asm: the statements are volatile
+// (kept in program order) and every caller keeps at least two other instructions between the write of `src` and
+// this read (see the 16x16 routine; s_nop 1 would cost 8 cycles each).
+template <int J>
+__device__ __forceinline__ void fmac_share(double &acc, double src, double mul) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(mul), "n"(J));
+}
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// A_ij -= L_i,ko L_j,ko'  for one 16x16 tile of the 64x64 block in LDS (ko = first column of the source block column)
+__device__ __forceinline__ void block16_update(double *__restrict__ A, int i, int j, int ko, int lr, int lq) {
+  d4_t c;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) c[rr] = A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+    c = mfma_f64(-A[(i * 16 + lr) * DLD + ko + 4 * s4 + lq], A[(j * 16 + lr) * DLD + ko + 4 * s4 + lq], c);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) A[(i * 16 + lq + 4 * rr) * DLD + j * 16 + lr] = c[rr];
+}
+
+
+// A: [64][DLD] the block (lower part meaningful; VAR 1 expects I_16 in rows 0..15 x columns 48..63), X: [64][DLD]
+// zero on entry, T: [32][TLD] scratch.  On return (after the closing barrier) A's lower triangle is L_pp and X is
+// inv(L_pp) (zero above the diagonal).  A non-positive / NaN / subnormal pivot is reported dpotrf-style through
+// info[0] (1-based global row, first failure wins); the arithmetic after it is garbage the host discards.
+// 256 threads, every thread calls.  stamps (nullable unless STAMP): s_memtime phase stamps, slots 2..17.
+template <int VAR, bool STAMP>
+__device__ __forceinline__ void diag_core(double *__restrict__ A, double *__restrict__ X, double *__restrict__ T, int p,
+                                          int *__restrict__ info, unsigned long long *__restrict__ stamps) {
+#define B7_DIAG_STAMP(i) \
+  if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int kb = 0; kb < 4; ++kb) {
+    const int o = kb * 16;
+    if (VAR == 1 && wave == 0) {
+      // Square-root-free pivot chain, built for ISSUE cycles: one wave issues a VALU instruction every ~5 cycles
+      // and this routine is bound by that, not by latency (tools/valu_probe.hip).  Lane lr keeps row lr of
+      // C = L diag(sqrt(d)) (c_ij = l_ij sqrt(d_j), pivots d_j = c_jj).  Per column j: broadcast d_j, r_j = 1/d_j
+      // (estimate + 2 Newton steps), one multiplier -c_ij r_j, then one fused DPP multiply-add per remaining column.
+      // Row j of the UNIT-lower inverse (of C diag(r)) needs only r, so it rides along in the same block of
+      // straight-line code; the 16 values y_j = 1/sqrt(d_j) that turn C and that inverse into L and inv(L) are
+      // computed once, lane j doing y_j from the pivot it captured, and broadcast.  No branch inside the chain:
+      // a non-positive (or NaN) pivot is found afterwards from the captured pivots; the arithmetic after it is
+      // garbage that the host discards together with this attempt.
+      // The recurrence that inverts the block, s_j = rhs_j - sum_{k<j} c_jk (r_k s_k), is a forward substitution
+      // with the identity as right-hand side.  The four 16-lane rows of the wave replicate the factorisation
+      // anyway (DPP broadcasts stay inside a row), so rows 1..3 run the SAME instructions on a different right-hand
+      // side: one row each of the sub-panel blocks below, which come out solved (L_ik = A_ik inv(L_kk)') for free.
+      double a[16], x[16], xs[16], rhs[16];
+      const int ib = kb + lq;  // sub-panel block of this lane row (lq >= 1); lane row 0 carries the inverse
+      const bool has_sub = lq > 0 && ib < 4;
+      // every lane reads its right-hand side through one pointer, no selects: the identity rows live in the
+      // block's unused upper-right corner (written before the loop), lane rows without a block read zeros from X's
+      // upper triangle
+      const double *rsrc = (lq == 0) ? A + lr * DLD + 48 : (has_sub ? A + (ib * 16 + lr) * DLD + o : X + 48);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        a[k] = A[(o + lr) * DLD + o + k];
+        rhs[k] = rsrc[k];
+      }
+      double dmine = 1.0;
+      static_for<16>([&](auto Jc) {
+        constexpr int j = Jc;
+        const double dj = row_share64<j>(a[j]);
+        dmine = (lr == j) ? dj : dmine;
+        double r = __builtin_amdgcn_rcp(dj);
+        r = __builtin_fma(__builtin_fma(-dj, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-dj, r, 1.0), r, r);
+        const double nm = -(a[j] * r);  // -l~_ij of the LDL' form (rows i > j)
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k > j) fmac_share<k>(a[k], a[j], nm);  // c_ik -= l~_ij c_kj; a[j] was last written >= 2 asm ago
+        });
+        // row j of the unit-lower inverse, lane lr holding column lr: x~_j = [j == lr] - sum_{k<j} c_jk (r_k x~_k)
+        double sacc = 0.0;
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k < j) fmac_share<j>(sacc, a[k], xs[k]);
+        });
+        x[j] = rhs[j] - sacc;
+        xs[j] = x[j] * r;
+      });
+      // also NaN, like dpotrf's test; a subnormal pivot counts as failed too (its reciprocal overflows)
+      const unsigned long long badmask = __ballot(!(dmine >= 2.2250738585072014e-308)) & 0xFFFFull;
+      if (badmask != 0 && lane == 0 && info[0] == 0) info[0] = p * NB + o + __ffsll((long long)badmask);
+      double ymine = __builtin_amdgcn_rsq(dmine);  // 1/sqrt(d_lr): hardware estimate + two Newton steps
+      const double hp = 0.5 * dmine;
+      ymine = ymine * __builtin_fma(-hp * ymine, ymine, 1.5);
+      ymine = ymine * __builtin_fma(-hp * ymine, ymine, 1.5);
+      static_for<16>([&](auto Kc) {
+        constexpr int k = Kc;
+        const double yk = row_share64<k>(ymine);
+        a[k] *= yk;  // L[lr][k] = c_lr,k / sqrt(d_k)
+        x[k] *= yk;  // lane row 0: inv(L)[k][lr] = s_k / sqrt(d_k); lane rows 1..3: L_ik[lr][k]
+      });
+      // one store loop for all lanes: lane row 0 writes its column of inv(L_kk) (stride DLD), rows 1..3 their
+      // solved sub-panel row (stride 1), rows without a block into an unused upper block of A (never read)
+      double *wdst = (lq == 0) ? X + o * DLD + o + lr : (has_sub ? A + (ib * 16 + lr) * DLD + o : A + lr * DLD + 32);
+      const int wstride = (lq == 0) ? DLD : 1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wdst[k * wstride] = x[k];
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
+      }
+    }
+    if (VAR == 1 && wave > 0 && kb > 0) {
+      // while wave 0 factors: the previous step's update of the tiles right of block column kb, with the previous
+      // step's panel (columns o - 16 ..).  kb = 1: (2,2) (3,2) (3,3); kb = 2: (3,3) again with panel 1; kb = 3: none.
+      // Nothing wave 0 touches in this phase (tile (kb,kb), the rows (i,kb) below it, X) is read or written here.
+      const int ko = o - 16;
+      if (kb == 1) {
+        const int i = wave == 1 ? 2 : 3, j = wave == 3 ? 3 : 2;
+        block16_update(A, i, j, ko, lr, lq);
+      } else if (kb == 2 && wave == 1) {
+        block16_update(A, 3, 3, ko, lr, lq);
+      } else if (kb == 2 && wave == 2) {
+        // inverse doubling 16 -> 32 of the pair (0,1): X_10 = -inv(L_11) * (L_10 * inv(L_00)); its inputs are final
+        d4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(A[(16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + lr], t);
+        d4_t xx = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) xx = mfma_f64(-X[(16 + lr) * DLD + 16 + 4 * s4 + lq], t[s4], xx);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) X[(16 + lq + 4 * rr) * DLD + lr] = xx[rr];
+      } else if (kb == 3) {
+        // first half of the doubling 32 -> 64: T = L[32:64, 0:32] * X[0:32, 0:32] (both final since step 2);
+        // tiles (ti, tj): wave 1 (0,0) and (0,1), wave 2 (1,0), wave 3 (1,1)
+        for (int q = 0; q < (wave == 1 ? 2 : 1); ++q) {
+          const int ti = wave == 1 ? 0 : 1, tj = wave == 1 ? q : wave - 2;
+          d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
+            t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
+        }
+      }
+    }
+    if (VAR == 0 && wave == 0) {
+      // every 16-lane row of the wave holds the same 16x16 sub-block (lane lr = matrix row lr)
+      double a[16], r[16], x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = A[(o + lr) * DLD + o + k];
+      static_for<16>([&](auto Jc) {
+        constexpr int j = Jc;
+        double pj = row_share<j>(a[j]);
+        if (!(pj > 0.0)) {  // also catches NaN, like dpotrf's test; uniform over the wave
+          if (lane == 0 && info[0] == 0) info[0] = p * NB + o + j + 1;
+          pj = 1.0;  // keep the arithmetic finite; the host discards this attempt
+        }
+        // 1/sqrt(pj): hardware estimate + two Newton steps (quadratic: 2^-26 -> full), then dj = pj * rj.
+        // LAPACK's dpotf2 likewise scales the column by the reciprocal of the pivot's root.
+        double y = __builtin_amdgcn_rsq(pj);
+        const double hp = 0.5 * pj;
+        y = y * __builtin_fma(-hp * y, y, 1.5);
+        y = y * __builtin_fma(-hp * y, y, 1.5);
+        r[j] = y;
+        const double dj = pj * y;
+        a[j] = (lr == j) ? dj : a[j] * y;
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k > j) {
+            const double lk = row_share<k>(a[j]);  // L[k][j]
+            a[k] -= a[j] * lk;                     // meaningful for rows >= k
+          }
+        });
+      });
+      // inverse: lane lr computes column lr of inv(L_kk); x[i] = X[i][lr]
+      static_for<16>([&](auto Ic) {
+        constexpr int i = Ic;
+        double sacc = 0.0;
+        static_for<16>([&](auto Kc) {
+          constexpr int k = Kc;
+          if constexpr (k < i) sacc += row_share<i>(a[k]) * x[k];  // L[i][k] * X[k][c]
+        });
+        x[i] = (i == lr) ? r[i] : ((i > lr) ? -(r[i] * sacc) : 0.0);
+      });
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
+          X[(o + k) * DLD + o + lr] = x[k];
+        }
+      }
+    }
+    B7_DIAG_STAMP(2 + 4 * kb);
+    __syncthreads();
+    B7_DIAG_STAMP(3 + 4 * kb);
+    // sub-panel: L_ik = A_ik * inv(L_kk)'  for block rows ib > kb, one 16x16 block per wave (VAR 1 solved it above)
+    if (VAR == 0) {
+      const int ib = kb + 1 + wave;
+      if (ib < 4) {
+        d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          c = mfma_f64(A[(ib * 16 + lr) * DLD + o + 4 * s4 + lq], X[(o + lr) * DLD + o + 4 * s4 + lq], c);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(ib * 16 + lq + 4 * rr) * DLD + o + lr] = c[rr];
+      }
+      __syncthreads();
+    }
+    B7_DIAG_STAMP(4 + 4 * kb);
+    // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4.  VAR 1 does only block column
+    // kb + 1 here (all the next factor step reads); the tiles right of it were left to waves 1..3 of the NEXT
+    // step's factor phase, where they idle anyway (see there).
+    if (VAR == 1) {
+      const int i = kb + 1 + wave;
+      if (i < 4) block16_update(A, i, kb + 1, o, lr, lq);
+    } else {
+      int pidx = 0;
+      for (int i = kb + 1; i < 4; ++i)
+        for (int j = kb + 1; j <= i; ++j, ++pidx) {
+          if ((pidx & 3) != wave) continue;
+          block16_update(A, i, j, o, lr, lq);
+        }
+    }
+    __syncthreads();
+    B7_DIAG_STAMP(5 + 4 * kb);
+  }
+
+  // What is left of the inverse doubling (VAR 1 did the pair (0,1) and T = L[32:64,0:32] X[0:32,0:32] inside the
+  // loop, on waves that were idle): the pair (2,3), then X[32:64, 0:32] = -X[32:64, 32:64] * T.
+  if (VAR == 1 ? wave == 0 : wave < 2) {
+    const int a0 = (VAR == 1 ? 1 : wave) * 32, c0 = a0 + 16;
+    d4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      t = mfma_f64(A[(c0 + lr) * DLD + a0 + 4 * s4 + lq], X[(a0 + 4 * s4 + lq) * DLD + a0 + lr], t);
+    d4_t xx = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) xx = mfma_f64(-X[(c0 + lr) * DLD + c0 + 4 * s4 + lq], t[s4], xx);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) X[(c0 + lq + 4 * rr) * DLD + a0 + lr] = xx[rr];
+  }
+  __syncthreads();
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    if (VAR == 0) {
+      d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
+        t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
+      __syncthreads();
+    }
+    d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      x0 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 32 + 4 * s4 + lq], T[(4 * s4 + lq) * TLD + tj * 16 + lr], x0);
+      x1 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 48 + 4 * s4 + lq], T[(16 + 4 * s4 + lq) * TLD + tj * 16 + lr], x1);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = x0[rr] + x1[rr];
+  }
+  __syncthreads();
+#undef B7_DIAG_STAMP
+}
+
+constexpr int DIAG_LDS_BYTES = (2 * NB * DLD + 32 * TLD) * 8;
+
+}  // namespace b7diag
