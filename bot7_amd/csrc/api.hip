@@ -138,6 +138,8 @@ int b7_create(b7_ctx **out, int device_id) {
   c->mlp_scalar = getenv("B7_MLP_SCALAR") != nullptr;
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
+  c->persist_stamps = getenv("B7_PERSIST_STAMPS") != nullptr;
+  if (const char *pv = getenv("B7_PERSIST_HELPERS")) c->persist_helpers = atoi(pv);
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
@@ -170,7 +172,7 @@ void b7_destroy(b7_ctx *c) {
   (void)b7_comm_destroy(c);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots};
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pjobs, &c->pflags, &c->pstamps};
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
     for (int i = 0; i < B7_MAX_TIMERS; ++i) {
@@ -361,6 +363,7 @@ int b7_gp_set_opts(b7_ctx *c, const b7_gp_opts *o) {
 
 // One factorisation attempt of K + extra*I; returns dpotrf-style info through *info.
 static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse);
+void persist_gave_up(b7_ctx *c);
 static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse);
 static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse);
 // device result block of a fit: int info[4] | double nll_terms[1 + 256]
@@ -451,14 +454,22 @@ int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_
   FitBlock &blk = *static_cast<FitBlock *>(c->pinned);  // pinned: the copy needs no pageable staging
   double *terms_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(c->info.p) + 16);
   const size_t blk_bytes = 16 + sizeof(double) * (nll_out ? 1 + ycols : 0);
-  B7_TRY(launch_potrf(c, 0.0, true));
-  bool tail_done = c->linv_done;
-  if (tail_done) {
-    B7_TRY(launch_alpha(c));
-    if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
+  bool tail_done = false;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    B7_TRY(launch_potrf(c, 0.0, true));
+    tail_done = c->linv_done;
+    if (tail_done) {
+      B7_TRY(launch_alpha(c));
+      if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
+    }
+    B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, tail_done ? blk_bytes : 16, hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (blk.info[1] == 0) break;
+    // the persistent schedule gave up on a hand-off (its workgroups were not all resident, e.g. the GPU is shared
+    // with another process's persistent kernel): same arithmetic through the launch schedule, which cannot stall
+    if (attempt == 1) return b7_fail(c, B7_ERR_HIP, "Cholesky: hand-off time-out (code %d) outside the persistent schedule", blk.info[1]);
+    persist_gave_up(c);
   }
-  B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, tail_done ? blk_bytes : 16, hipMemcpyDeviceToHost, c->stream));
-  B7_HIP(c, hipStreamSynchronize(c->stream));
   const int info_first = blk.info[0];
   double jitter = 0.0;
   if (info_first != 0) {
@@ -476,6 +487,7 @@ int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_
     for (int k = 0; k < ycols; ++k) nll_out[k] = 0.5 * blk.terms[1 + k] + blk.terms[0] + 0.5 * N * log(2.0 * M_PI);
   if (jitter_used) *jitter_used = jitter;
   if (info_out) *info_out = info_first;
+  if (c->potrf_sched_saved == 3 && c->persist_aborts < 3) c->potrf_sched = 3;
   c->fitted = true;
   return B7_OK;
 }
@@ -490,10 +502,29 @@ int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int yco
 
 }  // extern "C"
 
+// A persistent factorisation timed out on a hand-off: count it and use the launch schedule from here on (three strikes
+// switch this context over for good; the arithmetic is the same either way).
+void persist_gave_up(b7_ctx *c) {
+  c->persist_aborts += 1;
+  if (c->potrf_sched == 3) c->potrf_sched_saved = 3;
+  c->potrf_sched = 1;
+}
+static void persist_restore(b7_ctx *c) {
+  if (c->potrf_sched_saved == 3 && c->persist_aborts < 3) c->potrf_sched = 3;
+}
+
 static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse) {
-  B7_TRY(launch_potrf(c, extra, with_inverse));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
-  B7_HIP(c, hipMemcpyAsync(info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  B7_HIP(c, hipStreamSynchronize(c->stream));
+  int two[2] = {0, 0};
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    B7_TRY(launch_potrf(c, extra, with_inverse));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
+    B7_HIP(c, hipMemcpyAsync(two, c->info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (two[1] == 0) break;
+    if (attempt == 1) return b7_fail(c, B7_ERR_HIP, "Cholesky: hand-off time-out (code %d) outside the persistent schedule", two[1]);
+    persist_gave_up(c);
+  }
+  persist_restore(c);
+  *info = two[0];
   return B7_OK;
 }
 

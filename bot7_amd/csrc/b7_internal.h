@@ -90,7 +90,7 @@ struct b7_ctx {
   bool mlp_scalar = false;                       // force the scalar basis-network kernel (B7_MLP_SCALAR)
   int potrf_sched = 1;   // 1: one panel at a time (near update fused into the panel solve, far update riding on the
                          // next diagonal-block launch) for Npad <= 4096, 2: always; 0: panel groups with separate
-                         // update launches (B7_POTRF_SCHED)
+                         // update launches; 3: ONE persistent launch for Npad <= 2048, else as 1 (B7_POTRF_SCHED)
   int syrk_small = 1;    // whole-K single-stage kernel for trailing updates with <= 256 tiles (B7_SYRK_SMALL)
   int potrf_defer = 1;   // far part of each trailing update rides on the next diagonal-block launch (B7_POTRF_DEFER)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
@@ -98,6 +98,15 @@ struct b7_ctx {
   int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
   int post_variant = 9;  // posterior.hip launch_post: 9 = 128x256 tile, 8 waves, odd LDS stride, zero-strip skip, static
                          // priority raise for the younger half of the waves (B7_POST_VARIANT overrides)
+  // ---- persistent Cholesky schedule (potrf_persist.hip)
+  DevBuf pjobs;    // the job queue of the current (nb, with_inverse) shape
+  DevBuf pflags;   // hand-off flags, zeroed ahead of every launch
+  DevBuf pstamps;  // diagnostics (B7_PERSIST_STAMPS)
+  int pjobs_nb = 0, pjobs_inv = -1, pjobs_n = 0;
+  bool persist_attr_set = false, persist_stamps = false;
+  int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
+  int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
+  int potrf_sched_saved = 0; // the schedule to return to after such a redo
   DevBuf part;   // argmax partials (value, index)
   DevBuf scratch; // misc (fmin upload, results)
   DevBuf tmpgrid; // predict_at temporary grid
@@ -182,6 +191,7 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
 // potrf.hip
 int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I -> L, dinv, info (+ Linv, using W)
 int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
+int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse);  // the same in one persistent launch (Npad <= 2048)
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 int launch_nll_terms(b7_ctx *c, double *out_dev);  // out[0] = sum log L_ii, out[1 + k] = r_k' alpha_k
 int launch_fro_norm_sq(b7_ctx *c, const double *A, int n, int ld, double *out_dev);  // sum of squares of A[0:n, 0:n]

@@ -526,6 +526,7 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
 // own -- the factorisation is a chain of small dependent kernels that leaves most CUs idle.  Needs c->Linv and
 // c->W (n x n each).  Without it (b7_chol) only L and dinv are produced and launch_trtri is the way to inv(L).
 int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
+  if (c->potrf_sched == 3 && c->Npad <= 2048 && c->inverse_inline) return launch_potrf_persist(c, extra, with_inverse);
   PhaseScope ps(c, "potrf");
   const int n = c->Npad, nb = n / NB;
   double *L = (double *)c->L.p;
@@ -649,7 +650,7 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
   // and serial: measured potrf at N = 2048 is 1.07 ms for G = 1 and 2, 1.12 for 4, 1.27 for 8 (tools/potrf_ab.py).
   // measured pair schedule vs this one: 0.386 / 0.347 ms at N = 1024, 0.83 / 0.76 at 2048, 2.48 / 2.33 at 4096,
   // 12.2 / 12.6 at 8192 (K = 64 rider tiles by the thousand): one panel at a time up to Npad = 4096
-  if ((c->potrf_sched == 1 && n <= 4096) || c->potrf_sched == 2) {
+  if (((c->potrf_sched == 1 || c->potrf_sched == 3) && n <= 4096) || c->potrf_sched == 2) {
     // One panel at a time, two launches each, the rest riding along:
     //   diag(p)   + riders: partial products of inverse row p, and the FAR part of panel p-1's update (block columns
     //               >= p+1 ... i.e. everything but the column its own near part already did), K = 64 per tile

@@ -1,0 +1,641 @@
+// Blocked Cholesky + explicit inverse as ONE persistent launch with point-to-point hand-offs (Npad <= 2048).
+//
+// Same arithmetic as the per-panel launch schedule of potrf.hip, element for element (utils/math.lua:165 torch.potrf +
+// the inline inverse): every 64x64 tile (I, J) of the lower triangle is
+//     C_0 = K_IJ (+ eps on the diagonal),   C_{q+1} = C_q - L_Iq L_Jq'  for q = 0 .. J-1  (a 64-deep MFMA chain from
+//     zero, subtracted),   L_JJ = chol(C_J),   L_IJ = C_J inv(L_JJ)'  (the triangular chain of potrf_trsm_kernel<NEAR>),
+// and row block p of inv(L) is  -inv(L_pp) * sum over 128-deep K chunks (ascending) of L[p, kc] inv(L)[kc, j].
+// Only the SCHEDULE differs.  The launch schedule pays two dependent launches per panel (>= 4.2 us each before doing
+// anything); here the dependent chain lives inside one workgroup and everything else is pulled by
+// workgroups that wait on flags:
+//
+//   workgroup 0 ("critical"): for p = 0 .. nb-1: factor + invert the diagonal block in LDS (potrf_diag.h), publish
+//     L_pp and inv(L_pp); then the look-ahead that the next diagonal block waits for, without leaving the CU:
+//     L[p+1][p] = C(p+1, p) inv(L_pp)'  and  C(p+1, p+1) -= L[p+1][p] L[p+1][p]'.
+//   workgroups 1 .. H ("helpers"): pull tile jobs from one queue (an atomic counter over a list sorted by the panel at
+//     which a job can finish).  A job owns its tile in REGISTERS from C_0 to the end: it waits for the two L tiles of
+//     the next panel update (flags), applies it, and after the last one waits for inv(L_JJ) and publishes L_IJ.  Tiles
+//     (p, p-1) and (p, p) are brought up to panel p-2 by a helper and handed to the critical workgroup.  The tiles of
+//     inv(L) are jobs of the same kind; the structurally zero upper tiles are filled by the last jobs of the queue.
+//
+// Hand-offs follow cdna_hip_programming.md Guideline 16 in its write-through form: every byte another workgroup reads
+// inside the launch is stored with sc1 (buffer_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)), the
+// workgroup's barrier, then ONE lane stores the flag (agent-scope relaxed atomic = sc1 store); a consumer polls that
+// one word from one lane (relaxed agent loads, s_sleep between polls), joins its workgroup's barrier and reads the
+// bytes with sc1 loads only (they bypass the CU's L1, so no acquire fence).  One workgroup per CU (the LDS request
+// sees to that).  Every spin is bounded: a poller that gives up raises the launch's abort word, every other wait sees
+// it, all workgroups drain, and the host redoes the factorisation with the launch schedule.  Flags are zeroed by a
+// memset ahead of every launch.
+//
+// Every dependency of a queued job is either produced by the critical workgroup or by a job EARLIER in the queue, and
+// a popped job is held by a resident workgroup, so the queue cannot deadlock while workgroup 0 makes progress; workgroup
+// 0 in turn only waits for jobs whose inputs it has already published.
+#include <algorithm>
+#include <vector>
+
+#include "b7_internal.h"
+#include "gemm_f64.h"
+#include "potrf_diag.h"
+
+namespace {
+
+using namespace b7diag;
+using GT = GemmF64<64, 64, 64, 2, 2, false>;  // NT, all of K = 64 in one LDS stage (row stride 66 = DLD)
+using GN = GemmF64<64, 64, 32, 2, 2, true>;   // NN, 32-deep stages: the inverse's partial products (as potrf.hip's G64NN)
+static_assert(GT::STRIDE == DLD, "the trsm / look-ahead code reads GT's LDS image as [64][DLD]");
+
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+constexpr int FLAG_HDR = 16;                 // words: [0] queue head, [1] abort code, rest padding
+constexpr unsigned SPIN_LIMIT = 1u << 21;    // polls before a waiter gives up (>= 0.5 s)
+constexpr int PERSIST_LDS_BYTES = (3 * NB * DLD + 32 * TLD) * 8;  // A, X, T, S1 of the critical workgroup: 110 KiB
+static_assert(PERSIST_LDS_BYTES >= 2 * GT::STAGE_DOUBLES * 4 && PERSIST_LDS_BYTES > 80 * 1024, "one workgroup per CU");
+
+enum JobType { JOB_TILE = 0, JOB_PRE_SUB = 1, JOB_PRE_DIAG = 2, JOB_INV = 3, JOB_INV_DIAG = 4, JOB_ZERO = 5 };
+
+struct PArgs {
+  const double *K;
+  double *L, *Linv, *dinv;
+  unsigned *flags;
+  int *info;
+  unsigned long long *stamps;  // nullable: [nb][8] critical-path stamps, then [njobs][2] job start / end
+  const int4 *jobs;
+  int njobs, n, nb, nreal, with_inverse;
+  double extra;
+};
+
+// ---- flags ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ld_flag(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_flag(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct Flags {
+  unsigned *base;
+  int nb;
+  __device__ unsigned *head() const { return base; }
+  __device__ unsigned *abort_word() const { return base + 1; }
+  __device__ unsigned *ready(int I, int J) const { return base + FLAG_HDR + I * nb + J; }
+  __device__ unsigned *iready(int p, int j) const { return base + FLAG_HDR + nb * nb + p * nb + j; }
+  __device__ unsigned *pre_sub(int p) const { return base + FLAG_HDR + 2 * nb * nb + p; }
+  __device__ unsigned *pre_diag(int p) const { return base + FLAG_HDR + 2 * nb * nb + nb + p; }
+};
+
+// One lane polls ONE word, the workgroup learns the outcome through LDS.  false = abort (uniform): the caller returns.
+__device__ __forceinline__ bool wg_wait(unsigned *flag, const Flags &F, int *info, int *sh_ok, int code) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    while (ld_flag(flag) == 0u) {
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 255u) == 0u && ld_flag(F.abort_word()) != 0u) {
+        ok = 0;
+        break;
+      }
+      if (spins > SPIN_LIMIT) {  // give up: everybody drains, the host falls back to the launch schedule
+        st_flag(F.abort_word(), (unsigned)code);
+        __hip_atomic_store(info + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *sh_ok = ok;
+  }
+  __syncthreads();
+  const int ok = *sh_ok;
+  __syncthreads();  // sh_ok may be rewritten by the next wait
+  return ok != 0;
+}
+
+// Every storing wave drains, the workgroup meets, ONE lane raises the flag (Guideline 16, R1).
+__device__ __forceinline__ void wg_publish(unsigned *flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) st_flag(flag, 1u);
+}
+
+// ---- 64x64 tiles: thread t owns the 16-byte chunks c = t + 256 i (row c >> 5, columns 2 (c & 31) ..) -----------------
+struct Tile8 {
+  d2_t v[8];
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double *base) {
+  const unsigned long long a = (unsigned long long)base;  // wave-uniform by construction: make that provable
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ d2_t ld16_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  const u4_t x = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);  // aux 16 = sc1: bypasses this CU's L1
+  d2_t r;
+  r[0] = __hiloint2double((int)x[1], (int)x[0]);
+  r[1] = __hiloint2double((int)x[3], (int)x[2]);
+  return r;
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, d2_t v) {
+  u4_t x;
+  x[0] = (unsigned)__double2loint(v[0]);
+  x[1] = (unsigned)__double2hiint(v[0]);
+  x[2] = (unsigned)__double2loint(v[1]);
+  x[3] = (unsigned)__double2hiint(v[1]);
+  __builtin_amdgcn_raw_buffer_store_b128(x, rs, byte_off, 0, 16);  // write-through
+}
+__device__ __forceinline__ void tile_load_sc1(d2_t (&v)[8], const double *base, int ld) {
+  const __amdgpu_buffer_rsrc_t rs = tile_rsrc(base);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    v[i] = ld16_sc1(rs, ((c >> 5) * ld + 2 * (c & 31)) * 8);
+  }
+}
+__device__ __forceinline__ void tile_load_plain(d2_t (&v)[8], const double *base, int ld) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    v[i] = *reinterpret_cast<const d2_t *>(base + (int64_t)(c >> 5) * ld + 2 * (c & 31));
+  }
+}
+__device__ __forceinline__ void tile_store_sc1(const d2_t (&v)[8], double *base, int ld) {
+  const __amdgpu_buffer_rsrc_t rs = tile_rsrc(base);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    st16_sc1(rs, ((c >> 5) * ld + 2 * (c & 31)) * 8, v[i]);
+  }
+}
+__device__ __forceinline__ void tile_store_plain(const d2_t (&v)[8], double *base, int ld) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    *reinterpret_cast<d2_t *>(base + (int64_t)(c >> 5) * ld + 2 * (c & 31)) = v[i];
+  }
+}
+// registers <-> an LDS image [64][DLD] (16-byte aligned rows: DLD is even)
+__device__ __forceinline__ void tile_to_lds(const d2_t (&v)[8], double *img) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    *reinterpret_cast<d2_t *>(img + (c >> 5) * DLD + 2 * (c & 31)) = v[i];
+  }
+}
+__device__ __forceinline__ void tile_from_lds(d2_t (&v)[8], const double *img) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    v[i] = *reinterpret_cast<const d2_t *>(img + (c >> 5) * DLD + 2 * (c & 31));
+  }
+}
+
+// the accumulator layout of GT / GN (both 2 x 2 waves of 2 x 2 MFMA tiles): element (i, j, r) of this lane
+__device__ __forceinline__ int acc_row(int i, int r) { return GT::out_row(i, r); }
+__device__ __forceinline__ int acc_col(int j) { return GT::out_col(j); }
+
+// ---- the critical workgroup -------------------------------------------------------------------------------------------
+// copy_lower_kernel's view of a diagonal tile of K: the tile as assembled, eps added to the first nreal diagonal entries
+__device__ __forceinline__ void add_extra(d2_t (&v)[8], int tile, int nreal, double extra) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + 256 * i, row = c >> 5, col = 2 * (c & 31);
+    if (tile * NB + row < nreal) {
+      if (col == row) v[i][0] = v[i][0] + extra;
+      if (col + 1 == row) v[i][1] = v[i][1] + extra;
+    }
+  }
+}
+// VAR 1 of the factor routine keeps I_16 in rows 0..15 x columns 48..63 of the block image
+__device__ __forceinline__ void put_identity_corner(double *A) {
+  const int t = threadIdx.x;
+  A[(t >> 4) * DLD + 48 + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+}
+
+__device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *sh_ok) {
+  double *A = dsm, *X = dsm + NB * DLD, *T = X + NB * DLD, *S1 = T + 32 * TLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int n = a.n, nb = a.nb;
+  unsigned long long *st = a.stamps;
+#define PST(p, i) \
+  if (st && tid == 0) st[(p) * 8 + (i)] = __builtin_amdgcn_s_memtime()
+  {
+    d2_t v[8];
+    tile_load_plain(v, a.K, n);
+    add_extra(v, 0, a.nreal, a.extra);
+    tile_to_lds(v, A);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i][0] = v[i][1] = 0.0;
+    tile_to_lds(v, X);  // zero once: every round rewrites X's lower triangle in full and never touches the upper one
+  }
+  __syncthreads();
+  put_identity_corner(A);
+  __syncthreads();
+  for (int p = 0; p < nb; ++p) {
+    PST(p, 0);
+    diag_core<1, false>(A, X, T, p, a.info, nullptr);
+    PST(p, 1);
+    const bool last = p + 1 == nb;
+    d2_t d1[8];
+    // the tile below comes first so that its latency overlaps the stores of L_pp and inv(L_pp) issued behind it
+    if (!last) {
+      if (p == 0) {
+        tile_load_plain(d1, a.K + (int64_t)NB * n, n);
+      } else {
+        if (!wg_wait(F.pre_sub(p + 1), F, a.info, sh_ok, 100 + p)) return;
+        tile_load_sc1(d1, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
+      }
+    }
+    PST(p, 2);
+    {  // L_pp (upper triangle zeroed) and inv(L_pp), write-through
+      d2_t va[8], vx[8];
+      tile_from_lds(va, A);
+      tile_from_lds(vx, X);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i, row = c >> 5, col = 2 * (c & 31);
+        if (col > row) va[i][0] = 0.0;
+        if (col + 1 > row) va[i][1] = 0.0;
+      }
+      tile_store_sc1(va, a.L + ((int64_t)p * NB) * n + (int64_t)p * NB, n);
+      tile_store_sc1(vx, a.dinv + (int64_t)p * NB * NB, NB);
+    }
+    if (last) {
+      wg_publish(F.ready(p, p));
+      break;
+    }
+    tile_to_lds(d1, S1);
+    __syncthreads();
+    PST(p, 3);
+    // L[p+1][p] = C inv(L_pp)': wave w rows 16 w .., all four column blocks; the chain of potrf_trsm_kernel<NEAR>
+    // (k ascending, whole 16-blocks above the diagonal of inv(L_pp) skipped)
+    d4_t lqv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ko = kq * 16 + 4 * s4 + lq;
+        const double aq = S1[(wave * 16 + lr) * DLD + ko];
+#pragma unroll
+        for (int jb = kq; jb < 4; ++jb) lqv[jb] = mfma_f64(aq, X[(jb * 16 + lr) * DLD + ko], lqv[jb]);
+      }
+    __syncthreads();  // every wave is done reading S1
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) S1[(wave * 16 + lq + 4 * rr) * DLD + jb * 16 + lr] = lqv[jb][rr];
+    __syncthreads();
+    PST(p, 4);
+    // L_pp and inv(L_pp) were issued a triangular solve ago: the drain inside the publish is (nearly) free by now
+    wg_publish(F.ready(p, p));
+    {
+      d2_t vl[8];
+      tile_from_lds(vl, S1);
+      tile_store_sc1(vl, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
+    }
+    // next diagonal block, brought up to panel p-1 by a helper: this lane's elements (row 16 s + lq + 4 rr, column
+    // 16 wave + lr) of slab s
+    d4_t cin[4];
+    {
+      const double *src;
+      if (p == 0) {
+        src = a.K + ((int64_t)NB) * n + NB;
+      } else {
+        if (!wg_wait(F.pre_diag(p + 1), F, a.info, sh_ok, 200 + p)) return;
+        src = a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = 16 * s + lq + 4 * rr, col = 16 * wave + lr;
+          double v;
+          if (p == 0) {
+            v = src[(int64_t)row * n + col];
+          } else {  // 8-byte sc1 load
+            const unsigned long long bits = __hip_atomic_load(
+                reinterpret_cast<const unsigned long long *>(src + (int64_t)row * n + col), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            v = __longlong_as_double((long long)bits);
+          }
+          if (row == col && (p + 1) * NB + row < a.nreal && p == 0) v = v + a.extra;  // helpers add eps to their C_0
+          cin[s][rr] = v;
+        }
+    }
+    PST(p, 5);
+    // C(p+1, p+1) -= L[p+1][p] L[p+1][p]': the 64-deep chain from zero, then the subtraction (syrk_tile / NEAR update)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      d4_t u = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4)
+        u = mfma_f64(S1[(16 * s + lr) * DLD + 4 * k4 + lq], S1[(wave * 16 + lr) * DLD + 4 * k4 + lq], u);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) A[(16 * s + lq + 4 * rr) * DLD + wave * 16 + lr] = cin[s][rr] - u[rr];
+    }
+    __syncthreads();
+    put_identity_corner(A);
+    PST(p, 6);
+    wg_publish(F.ready(p + 1, p));  // its barrier also orders the corner before the factor's first reads
+    PST(p, 7);
+  }
+#undef PST
+}
+
+// ---- helper jobs ------------------------------------------------------------------------------------------------------
+// C_{q+1} = C_q - L_Iq L_Jq': both tiles to LDS, one 64-deep chain per accumulator from zero, subtract.
+__device__ __forceinline__ void apply_update(d4_t (&C)[2][2], const double *Lq_I, const double *Lq_J, int n, double *sm) {
+  GT::Regs r;
+  tile_load_sc1(r.a, Lq_I, n);
+  tile_load_sc1(r.b, Lq_J, n);
+  GT::store_lds(r, sm);
+  __syncthreads();
+  d4_t P[2][2] = {};
+  GT::compute_stage(sm, P);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) C[i][j] = C[i][j] - P[i][j];
+}
+
+__device__ __forceinline__ void acc_to_lds(const d4_t (&C)[2][2], double *img, int stride) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[acc_row(i, r) * stride + acc_col(j)] = C[i][j][r];
+}
+
+// tile (I, J) of the lower triangle, I > J (type JOB_TILE / JOB_PRE_SUB) or I == J (JOB_PRE_DIAG)
+__device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J, double *sm, int *sh_ok) {
+  const int n = a.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  d4_t C[2][2];
+  {
+    const double *k0 = a.K + ((int64_t)I * NB) * n + (int64_t)J * NB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = acc_row(i, r), col = acc_col(j);
+          double v = k0[(int64_t)row * n + col];
+          if (I == J && row == col && I * NB + row < a.nreal) v = v + a.extra;
+          C[i][j][r] = v;
+        }
+  }
+  const int nupd = (type == JOB_PRE_DIAG) ? J - 1 : J;  // the critical workgroup applies panel J-1 to its own diagonal tile
+  for (int q = 0; q < nupd; ++q) {
+    if (!wg_wait(F.ready(I, q), F, a.info, sh_ok, 1000 + I * 64 + q)) return false;
+    if (I != J && !wg_wait(F.ready(J, q), F, a.info, sh_ok, 1000 + J * 64 + q)) return false;
+    apply_update(C, a.L + ((int64_t)I * NB) * n + (int64_t)q * NB, a.L + ((int64_t)J * NB) * n + (int64_t)q * NB, n, sm);
+  }
+  double *Ai = sm, *Xp = sm + NB * DLD;
+  double *dst = a.L + ((int64_t)I * NB) * n + (int64_t)J * NB;
+  acc_to_lds(C, Ai, DLD);
+  if (type == JOB_TILE) {
+    if (!wg_wait(F.ready(J, J), F, a.info, sh_ok, 5000 + J)) return false;
+    d2_t vx[8];
+    tile_load_sc1(vx, a.dinv + (int64_t)J * NB * NB, NB);
+    tile_to_lds(vx, Xp);
+    __syncthreads();
+    // L_IJ = C inv(L_JJ)': slab s rows 16 s .., wave w column block w, k-blocks above the diagonal skipped
+    d4_t li[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      if (kq > wave) break;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ko = kq * 16 + 4 * s4 + lq;
+        const double xb = Xp[(wave * 16 + lr) * DLD + ko];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) li[s] = mfma_f64(Ai[(16 * s + lr) * DLD + ko], xb, li[s]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ai[(16 * s + lq + 4 * rr) * DLD + wave * 16 + lr] = li[s][rr];
+  }
+  __syncthreads();
+  d2_t vo[8];
+  tile_from_lds(vo, Ai);
+  tile_store_sc1(vo, dst, n);
+  wg_publish(type == JOB_TILE ? F.ready(I, J) : (type == JOB_PRE_SUB ? F.pre_sub(I) : F.pre_diag(I)));
+  __syncthreads();  // the staging area is free for the next job
+  return true;
+}
+
+// tile (p, j), j < p, of inv(L)
+__device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm, int *sh_ok) {
+  const int n = a.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  d4_t tot[2][2] = {}, cur[2][2] = {};
+  for (int t = j; t < p; ++t) {
+    if (!wg_wait(F.ready(p, t), F, a.info, sh_ok, 10000 + p * 64 + t)) return false;
+    if (!wg_wait(t == j ? F.ready(j, j) : F.iready(t, j), F, a.info, sh_ok, 20000 + t * 64 + j)) return false;
+    const double *Lpt = a.L + ((int64_t)p * NB) * n + (int64_t)t * NB;
+    // rows [64 t, 64 t + 64) x columns [64 j, ..) of inv(L); the diagonal tile is inv(L_jj) itself
+    const double *Btile = (t == j) ? a.dinv + (int64_t)j * NB * NB : a.Linv + ((int64_t)t * NB) * n + (int64_t)j * NB;
+    const int ldb = (t == j) ? NB : n;
+    const __amdgpu_buffer_rsrc_t ra = tile_rsrc(Lpt), rb = tile_rsrc(Btile);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // two 32-deep stages, the chain runs on through both (and through a chunk's 2nd tile)
+      GN::Regs r;
+#pragma unroll
+      for (int i = 0; i < GN::A_PER_T; ++i) {
+        const int c = tid + i * 256, row = c / 16, kc = c % 16;
+        r.a[i] = ld16_sc1(ra, (row * n + 32 * h + 2 * kc) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < GN::B_PER_T; ++i) {
+        const int c = tid + i * 256, kr = c / 32, nc = c % 32;
+        r.b[i] = ld16_sc1(rb, ((32 * h + kr) * ldb + 2 * nc) * 8);
+      }
+      GN::store_lds(r, sm);
+      __syncthreads();
+      GN::compute_stage(sm, cur);
+      __syncthreads();
+    }
+    if ((t & 1) == 1 || t == p - 1) {  // end of the 128-deep chunk t / 2: partials are summed in ascending chunk order
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          tot[i][jj] = tot[i][jj] + cur[i][jj];
+          cur[i][jj] = d4_t{0.0, 0.0, 0.0, 0.0};
+        }
+    }
+  }
+  if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, 30000 + p)) return false;
+  constexpr int SLD = 65;  // odd stride: the B-operand reads (k = lane >> 4, n = lane & 15) stay conflict-free
+  double *Dn = sm, *Ts = sm + NB * DLD;
+  {
+    d2_t vd[8];
+    tile_load_sc1(vd, a.dinv + (int64_t)p * NB * NB, NB);
+    tile_to_lds(vd, Dn);
+  }
+  acc_to_lds(tot, Ts, SLD);
+  __syncthreads();
+  // out = -inv(L_pp) * sum: wave w owns rows 16 w ..; two accumulators alternate (potrf_trsm_kernel's inverse rows)
+  d4_t outv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    d4_t c0a = {0.0, 0.0, 0.0, 0.0}, c1a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      if (kq > wave) break;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4 += 2) {
+        c0a = mfma_f64(-Dn[(wave * 16 + lr) * DLD + kq * 16 + 4 * s4 + lq], Ts[(kq * 16 + 4 * s4 + lq) * SLD + 16 * s + lr], c0a);
+        c1a = mfma_f64(-Dn[(wave * 16 + lr) * DLD + kq * 16 + 4 * s4 + 4 + lq],
+                       Ts[(kq * 16 + 4 * s4 + 4 + lq) * SLD + 16 * s + lr], c1a);
+      }
+    }
+    outv[s] = c0a + c1a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Dn[(wave * 16 + lq + 4 * rr) * DLD + 16 * s + lr] = outv[s][rr];
+  __syncthreads();
+  d2_t vo[8];
+  tile_from_lds(vo, Dn);
+  tile_store_sc1(vo, a.Linv + ((int64_t)p * NB) * n + (int64_t)j * NB, n);
+  wg_publish(F.iready(p, j));
+  __syncthreads();
+  return true;
+}
+
+__global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
+  extern __shared__ __align__(16) double dsm[];
+  __shared__ int sh_ok, sh_job;
+  const Flags F{a.flags, a.nb};
+  if (blockIdx.x == 0) {
+    critical_path(a, F, dsm, &sh_ok);
+    return;
+  }
+  const int n = a.n;
+  for (;;) {
+    if (threadIdx.x == 0)
+      sh_job = (int)__hip_atomic_fetch_add(F.head(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int jid = __builtin_amdgcn_readfirstlane(sh_job);
+    __syncthreads();
+    if (jid >= a.njobs) return;
+    if (ld_flag(F.abort_word()) != 0u) return;  // uniform: every lane reads the same word
+    const int4 job = a.jobs[jid];
+    const int type = __builtin_amdgcn_readfirstlane(job.x), I = __builtin_amdgcn_readfirstlane(job.y),
+              J = __builtin_amdgcn_readfirstlane(job.z);
+    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 2] = __builtin_amdgcn_s_memtime();
+    bool ok = true;
+    if (type == JOB_TILE || type == JOB_PRE_SUB || type == JOB_PRE_DIAG) {
+      ok = tile_job(a, F, type, I, J, dsm, &sh_ok);
+    } else if (type == JOB_INV) {
+      ok = inv_job(a, F, I, J, dsm, &sh_ok);
+    } else if (type == JOB_INV_DIAG) {  // inv(L)[p][p] = inv(L_pp): nobody inside the launch reads it
+      ok = wg_wait(F.ready(I, I), F, a.info, &sh_ok, 40000 + I);
+      if (ok) {
+        d2_t v[8];
+        tile_load_sc1(v, a.dinv + (int64_t)I * NB * NB, NB);
+        tile_store_plain(v, a.Linv + ((int64_t)I * NB) * n + (int64_t)I * NB, n);
+      }
+    } else {  // JOB_ZERO: a structurally zero tile above the diagonal, in L and in inv(L)
+      d2_t z[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) z[i][0] = z[i][1] = 0.0;
+      tile_store_plain(z, a.L + ((int64_t)I * NB) * n + (int64_t)J * NB, n);
+      if (a.with_inverse) tile_store_plain(z, a.Linv + ((int64_t)I * NB) * n + (int64_t)J * NB, n);
+    }
+    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 2 + 1] = __builtin_amdgcn_s_memtime();
+    if (!ok) return;
+  }
+}
+
+struct HostJob {
+  int type, I, J;
+  double key;
+};
+
+}  // namespace
+
+// K + extra*I -> L, dinv, info (+ Linv) in one persistent launch.  The caller has checked Npad <= 2048.
+int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
+  PhaseScope ps(c, "potrf");
+  const int n = c->Npad, nb = n / NB;
+  c->linv_done = false;
+  if (c->pjobs_nb != nb || c->pjobs_inv != (with_inverse ? 1 : 0)) {
+    // the queue: sorted by the panel at whose end a job can finish; every dependency of a job is produced by workgroup 0
+    // or sits earlier in this order
+    std::vector<HostJob> jobs;
+    for (int J = 0; J < nb; ++J)
+      for (int I = J + 2; I < nb; ++I) jobs.push_back({JOB_TILE, I, J, J + 0.001 * (I - J)});
+    for (int p = 2; p < nb; ++p) jobs.push_back({JOB_PRE_SUB, p, p - 1, (p - 1) - 0.6});
+    for (int p = 2; p < nb; ++p) jobs.push_back({JOB_PRE_DIAG, p, p, (p - 1) - 0.55});
+    if (with_inverse) {
+      for (int p = 1; p < nb; ++p)
+        for (int j = 0; j < p; ++j) jobs.push_back({JOB_INV, p, j, p + 0.5 + 0.001 * (p - j)});
+      for (int p = 0; p < nb; ++p) jobs.push_back({JOB_INV_DIAG, p, p, p + 0.9});
+    }
+    for (int I = 0; I < nb; ++I)
+      for (int J = I + 1; J < nb; ++J) jobs.push_back({JOB_ZERO, I, J, 1e9});
+    std::stable_sort(jobs.begin(), jobs.end(), [](const HostJob &x, const HostJob &y) { return x.key < y.key; });
+    std::vector<int4> packed(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) packed[i] = make_int4(jobs[i].type, jobs[i].I, jobs[i].J, 0);
+    B7_TRY(b7_ensure(c, c->pjobs, sizeof(int4) * (packed.size() + 1)));
+    B7_HIP(c, hipMemcpy(c->pjobs.p, packed.data(), sizeof(int4) * packed.size(), hipMemcpyHostToDevice));
+    c->pjobs_n = (int)packed.size();
+    c->pjobs_nb = nb;
+    c->pjobs_inv = with_inverse ? 1 : 0;
+  }
+  const size_t flag_words = (size_t)round_up(FLAG_HDR + 2 * nb * nb + 2 * nb, 4);
+  B7_TRY(b7_ensure(c, c->pflags, sizeof(unsigned) * flag_words));
+  if (!c->persist_attr_set) {
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_persist_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS_BYTES));
+    c->persist_attr_set = true;
+  }
+  B7_HIP(c, hipMemsetAsync(c->pflags.p, 0, sizeof(unsigned) * flag_words, c->stream));
+  B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
+  PArgs a;
+  a.K = (const double *)c->K.p;
+  a.L = (double *)c->L.p;
+  a.Linv = with_inverse ? (double *)c->Linv.p : nullptr;
+  a.dinv = (double *)c->dinv.p;
+  a.flags = (unsigned *)c->pflags.p;
+  a.info = (int *)c->info.p;
+  a.stamps = nullptr;
+  if (c->persist_stamps) {
+    B7_TRY(b7_ensure(c, c->pstamps, sizeof(unsigned long long) * ((size_t)nb * 8 + (size_t)c->pjobs_n * 2)));
+    B7_HIP(c, hipMemsetAsync(c->pstamps.p, 0, sizeof(unsigned long long) * ((size_t)nb * 8 + (size_t)c->pjobs_n * 2),
+                             c->stream));
+    a.stamps = (unsigned long long *)c->pstamps.p;
+  }
+  a.jobs = (const int4 *)c->pjobs.p;
+  a.njobs = c->pjobs_n;
+  a.n = n;
+  a.nb = nb;
+  a.nreal = c->N;
+  a.with_inverse = with_inverse ? 1 : 0;
+  a.extra = extra;
+  // one workgroup per CU (the LDS request guarantees it); all of them must be resident at once, so never more than CUs
+  int helpers = c->pjobs_n < c->cus - 1 ? c->pjobs_n : c->cus - 1;
+  if (c->persist_helpers > 0 && c->persist_helpers < helpers) helpers = c->persist_helpers;
+  hipLaunchKernelGGL(potrf_persist_kernel, dim3(1 + helpers), dim3(256), PERSIST_LDS_BYTES, c->stream, a);
+  B7_HIP(c, hipGetLastError());
+  c->linv_done = with_inverse;
+  return B7_OK;
+}
+
+// diagnostics (tools/persist_stamps.py): the stamps of the last persistent launch, [nb][8] then [njobs][2]
+int b7_internal_persist_stamps(b7_ctx *c, unsigned long long *out, int max_words, int *nb_out, int *njobs_out) {
+  if (!c->pstamps.p) return B7_ERR_STATE;
+  const int words = c->pjobs_nb * 8 + c->pjobs_n * 2;
+  if (nb_out) *nb_out = c->pjobs_nb;
+  if (njobs_out) *njobs_out = c->pjobs_n;
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  B7_HIP(c, hipMemcpy(out, c->pstamps.p, sizeof(unsigned long long) * (words < max_words ? words : max_words),
+                      hipMemcpyDeviceToHost));
+  return B7_OK;
+}
