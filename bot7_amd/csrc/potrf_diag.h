@@ -75,9 +75,16 @@ __device__ __forceinline__ void block16_update(double *__restrict__ A, int i, in
 // inv(L_pp) (zero above the diagonal).  A non-positive / NaN / subnormal pivot is reported dpotrf-style through
 // info[0] (1-based global row, first failure wins); the arithmetic after it is garbage the host discards.
 // 256 threads, every thread calls.  stamps (nullable unless STAMP): s_memtime phase stamps, slots 2..17.
-template <int VAR, bool STAMP>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int, int) const {}
+};
+// hook(kb, wave) runs on waves 1..3 (VAR 1) at the end of their share of step kb's factor phase, i.e. in time they would
+// otherwise spend waiting for wave 0 at the phase's barrier (wave 3 has nothing else to do at kb = 2): the persistent
+// schedule fetches the next panel's tiles there.  It must not touch A, X or T.
+template <int VAR, bool STAMP, class Hook = NoHook>
 __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__restrict__ X, double *__restrict__ T, int p,
-                                          int *__restrict__ info, unsigned long long *__restrict__ stamps) {
+                                          int *__restrict__ info, unsigned long long *__restrict__ stamps,
+                                          const Hook &hook = Hook()) {
 #define B7_DIAG_STAMP(i) \
   if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -191,6 +198,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
           for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
         }
       }
+      hook(kb, wave);
     }
     if (VAR == 0 && wave == 0) {
       // every 16-lane row of the wave holds the same 16x16 sub-block (lane lr = matrix row lr)

@@ -48,7 +48,7 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 constexpr int FLAG_HDR = 16;                 // words: [0] queue head, [1] abort code, rest padding
 constexpr unsigned SPIN_LIMIT = 1u << 21;    // polls before a waiter gives up (>= 0.5 s)
-constexpr int PERSIST_LDS_BYTES = (3 * NB * DLD + 32 * TLD) * 8;  // A, X, T, S1 of the critical workgroup: 110 KiB
+constexpr int PERSIST_LDS_BYTES = (4 * NB * DLD + 32 * TLD) * 8;  // A, X, T, S1, S2 of the critical workgroup: 141 KiB
 static_assert(PERSIST_LDS_BYTES >= 2 * GT::STAGE_DOUBLES * 4 && PERSIST_LDS_BYTES > 80 * 1024, "one workgroup per CU");
 
 enum JobType { JOB_TILE = 0, JOB_PRE_SUB = 1, JOB_PRE_DIAG = 2, JOB_INV = 3, JOB_INV_DIAG = 4, JOB_ZERO = 5 };
@@ -208,9 +208,67 @@ __device__ __forceinline__ void put_identity_corner(double *A) {
   A[(t >> 4) * DLD + 48 + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
 }
 
-__device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *sh_ok) {
-  double *A = dsm, *X = dsm + NB * DLD, *T = X + NB * DLD, *S1 = T + 32 * TLD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+// Fetching the next panel's two tiles while the factorisation still runs: at step kb = 2 of the factor routine wave 3
+// has nothing to do and waves 1 and 2 little, so wave 3 brings tile (p+1, p) into S1 and waves 1 / 2 one half each of
+// tile (p+1, p+1) into S2 -- if the helpers have already handed them over (one non-blocking look at the flag; they
+// usually have, a couple of microseconds into the factorisation).  What was not fetched here is fetched after the
+// factorisation the blocking way.
+struct Prefetch {
+  const PArgs &a;
+  const Flags &F;
+  double *S1, *S2;
+  int *done;  // LDS: [0] tile below in S1, [1] / [2] upper / lower half of the next diagonal tile in S2
+  int p;
+  __device__ __forceinline__ void rows(const double *src, bool plain, double *img, int row0, int nrows, int tile,
+                                       bool diag) const {
+    const int lane = threadIdx.x & 63, n = a.n;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(src);
+    for (int i0 = 0; i0 < nrows / 2; i0 += 16) {  // 16 chunks of 16 bytes in flight per lane
+      d2_t v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * (i0 + i), row = row0 + (c >> 5), col = 2 * (c & 31);
+        v[i] = plain ? *reinterpret_cast<const d2_t *>(src + (int64_t)row * n + col) : ld16_sc1(rs, (row * n + col) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * (i0 + i), row = row0 + (c >> 5), col = 2 * (c & 31);
+        if (diag && plain && tile * NB + row < a.nreal) {  // C_0 of a diagonal tile read straight from K: + eps
+          if (col == row) v[i][0] = v[i][0] + a.extra;
+          if (col + 1 == row) v[i][1] = v[i][1] + a.extra;
+        }
+        *reinterpret_cast<d2_t *>(img + row * DLD + col) = v[i];
+      }
+    }
+  }
+  __device__ __forceinline__ void operator()(int kb, int wave) const {
+    if (kb != 2 || p + 1 >= a.nb) return;
+    const int n = a.n, lane = threadIdx.x & 63;
+    const bool fromK = p == 0;  // panel 0's neighbours have no earlier panel to wait for
+    if (wave == 3) {
+      if (!fromK && ld_flag(F.pre_sub(p + 1)) == 0u) return;
+      const double *src = fromK ? a.K + (int64_t)NB * n : a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB;
+      rows(src, fromK, S1, 0, 64, p + 1, false);
+      if (lane == 0) done[0] = 1;
+    } else {
+      if (!fromK && ld_flag(F.pre_diag(p + 1)) == 0u) return;
+      const double *src = fromK ? a.K + (int64_t)NB * n + NB : a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB;
+      rows(src, fromK, S2, wave == 1 ? 0 : 32, 32, p + 1, true);
+      if (lane == 0) done[wave] = 1;
+    }
+  }
+};
+
+// the ten 16x16 sub-tiles (slab s, column block cb), cb <= s, of the next diagonal block, three / three / two / two to
+// a wave; the six above the diagonal are never read by the factor routine and keep whatever the last round left there
+__device__ constexpr int SUB_N[4] = {3, 3, 2, 2};
+__device__ constexpr int SUB_S[4][3] = {{0, 1, 2}, {3, 1, 2}, {3, 2, 0}, {3, 3, 0}};
+__device__ constexpr int SUB_C[4][3] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 0}, {2, 3, 0}};
+
+__device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *sh_ok, int *pf_done) {
+  double *A = dsm, *X = dsm + NB * DLD, *T = X + NB * DLD, *S1 = T + 32 * TLD, *S2 = S1 + NB * DLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15,
+            lq = lane >> 4;
   const int n = a.n, nb = a.nb;
   unsigned long long *st = a.stamps;
 #define PST(p, i) \
@@ -224,22 +282,34 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     for (int i = 0; i < 8; ++i) v[i][0] = v[i][1] = 0.0;
     tile_to_lds(v, X);  // zero once: every round rewrites X's lower triangle in full and never touches the upper one
   }
+  if (tid < 4) pf_done[tid] = 0;
   __syncthreads();
   put_identity_corner(A);
   __syncthreads();
   for (int p = 0; p < nb; ++p) {
     PST(p, 0);
-    diag_core<1, false>(A, X, T, p, a.info, nullptr);
+    diag_core<1, false>(A, X, T, p, a.info, nullptr, Prefetch{a, F, S1, S2, pf_done, p});
     PST(p, 1);
     const bool last = p + 1 == nb;
+    const bool have_d1 = pf_done[0] != 0, have_d2 = pf_done[1] != 0 && pf_done[2] != 0;
     d2_t d1[8];
-    // the tile below comes first so that its latency overlaps the stores of L_pp and inv(L_pp) issued behind it
-    if (!last) {
+    // what the prefetch did not get, first (its latency overlaps the stores of L_pp and inv(L_pp) issued behind it)
+    if (!last && !have_d1) {
       if (p == 0) {
         tile_load_plain(d1, a.K + (int64_t)NB * n, n);
       } else {
         if (!wg_wait(F.pre_sub(p + 1), F, a.info, sh_ok, 100 + p)) return;
         tile_load_sc1(d1, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
+      }
+    }
+    d2_t d2[8];
+    if (!last && !have_d2) {
+      if (p == 0) {
+        tile_load_plain(d2, a.K + (int64_t)NB * n + NB, n);
+        add_extra(d2, 1, a.nreal, a.extra);
+      } else {
+        if (!wg_wait(F.pre_diag(p + 1), F, a.info, sh_ok, 200 + p)) return;
+        tile_load_sc1(d2, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB, n);
       }
     }
     PST(p, 2);
@@ -260,8 +330,10 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       wg_publish(F.ready(p, p));
       break;
     }
-    tile_to_lds(d1, S1);
-    __syncthreads();
+    if (!have_d1) tile_to_lds(d1, S1);
+    if (!have_d2) tile_to_lds(d2, S2);
+    __syncthreads();  // also: everybody has read pf_done
+    if (tid < 4) pf_done[tid] = 0;
     PST(p, 3);
     // L[p+1][p] = C inv(L_pp)': wave w rows 16 w .., all four column blocks; the chain of potrf_trsm_kernel<NEAR>
     // (k ascending, whole 16-blocks above the diagonal of inv(L_pp) skipped)
@@ -289,45 +361,30 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       tile_from_lds(vl, S1);
       tile_store_sc1(vl, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
     }
-    // next diagonal block, brought up to panel p-1 by a helper: this lane's elements (row 16 s + lq + 4 rr, column
-    // 16 wave + lr) of slab s
-    d4_t cin[4];
+    PST(p, 5);
+    // C(p+1, p+1) -= L[p+1][p] L[p+1][p]': per 16x16 sub-tile the 64-deep chain from zero, then the subtraction
+    // (syrk_tile / NEAR update); this wave's sub-tiles run as interleaved chains
     {
-      const double *src;
-      if (p == 0) {
-        src = a.K + ((int64_t)NB) * n + NB;
-      } else {
-        if (!wg_wait(F.pre_diag(p + 1), F, a.info, sh_ok, 200 + p)) return;
-        src = a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB;
+      d4_t u[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      const int nsub = SUB_N[wave];
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (t < nsub)
+            u[t] = mfma_f64(S1[(16 * SUB_S[wave][t] + lr) * DLD + 4 * k4 + lq], S1[(16 * SUB_C[wave][t] + lr) * DLD + 4 * k4 + lq],
+                            u[t]);
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int t = 0; t < 3; ++t)
+        if (t < nsub) {
+          const int s = SUB_S[wave][t], cb = SUB_C[wave][t];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = 16 * s + lq + 4 * rr, col = 16 * wave + lr;
-          double v;
-          if (p == 0) {
-            v = src[(int64_t)row * n + col];
-          } else {  // 8-byte sc1 load
-            const unsigned long long bits = __hip_atomic_load(
-                reinterpret_cast<const unsigned long long *>(src + (int64_t)row * n + col), __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_AGENT);
-            v = __longlong_as_double((long long)bits);
+          for (int rr = 0; rr < 4; ++rr) {
+            const int e = (16 * s + lq + 4 * rr) * DLD + 16 * cb + lr;
+            A[e] = S2[e] - u[t][rr];
           }
-          if (row == col && (p + 1) * NB + row < a.nreal && p == 0) v = v + a.extra;  // helpers add eps to their C_0
-          cin[s][rr] = v;
         }
-    }
-    PST(p, 5);
-    // C(p+1, p+1) -= L[p+1][p] L[p+1][p]': the 64-deep chain from zero, then the subtraction (syrk_tile / NEAR update)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      d4_t u = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k4 = 0; k4 < 16; ++k4)
-        u = mfma_f64(S1[(16 * s + lr) * DLD + 4 * k4 + lq], S1[(wave * 16 + lr) * DLD + 4 * k4 + lq], u);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) A[(16 * s + lq + 4 * rr) * DLD + wave * 16 + lr] = cin[s][rr] - u[rr];
     }
     __syncthreads();
     put_identity_corner(A);
@@ -510,10 +567,10 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
 
 __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
   extern __shared__ __align__(16) double dsm[];
-  __shared__ int sh_ok, sh_job;
+  __shared__ int sh_ok, sh_job, pf_done[4];
   const Flags F{a.flags, a.nb};
   if (blockIdx.x == 0) {
-    critical_path(a, F, dsm, &sh_ok);
+    critical_path(a, F, dsm, &sh_ok, pf_done);
     return;
   }
   const int n = a.n;
@@ -629,7 +686,7 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
 }
 
 // diagnostics (tools/persist_stamps.py): the stamps of the last persistent launch, [nb][8] then [njobs][2]
-int b7_internal_persist_stamps(b7_ctx *c, unsigned long long *out, int max_words, int *nb_out, int *njobs_out) {
+extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_words, int *nb_out, int *njobs_out) {
   if (!c->pstamps.p) return B7_ERR_STATE;
   const int words = c->pjobs_nb * 8 + c->pjobs_n * 2;
   if (nb_out) *nb_out = c->pjobs_nb;

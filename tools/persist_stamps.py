@@ -1,0 +1,49 @@
+"""Where the persistent Cholesky's critical workgroup spends its time, and when the helper jobs run (s_memtime stamps,
+B7_PERSIST_STAMPS=1).   python tools/persist_stamps.py [N]
+Critical path per panel p (cycles of the 100 MHz... no: s_memtime ticks = shader cycles at ~2.4 GHz under light load):
+  0 factor start | 1 factor end | 2 tile-below load issued (after its flag) | 3 tile in LDS | 4 trsm done |
+  5 next diagonal block loaded (after its flag) | 6 update done | 7 published"""
+import ctypes as C
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["B7_POTRF_SCHED"] = "3"
+os.environ["B7_PERSIST_STAMPS"] = "1"
+import bot7_amd  # noqa: E402
+from bot7_amd import benchmarks, _lib  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+d = 32
+c = bot7_amd.Context(0)
+X = c.grid_sobol(N, d, 2)
+Y = benchmarks.ackley(X)
+amp = float(np.var(Y))
+hyp = (np.full(d, d / 8.0), amp, 1e-4 * amp, float(np.mean(Y)))
+for _ in range(3):
+    c.gp_fit(X, Y, *hyp)
+L = _lib.load()
+buf = np.zeros(1 << 16, dtype=np.uint64)
+nb, nj = C.c_int(), C.c_int()
+rc = L.b7dbg_persist_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(nb), C.byref(nj))
+assert rc == 0, rc
+nb, nj = nb.value, nj.value
+crit = buf[:nb * 8].reshape(nb, 8).astype(np.int64)
+jobs = buf[nb * 8:nb * 8 + nj * 2].reshape(nj, 2).astype(np.int64)
+t0 = crit[0, 0]
+GHZ = 2.4
+names = ["factor", "wait+issue D1", "stores+D1->LDS", "trsm", "wait+load D2", "update", "publish"]
+print("panel  start_us  " + "  ".join("%-14s" % s for s in names) + "  total_us")
+tot = np.zeros(7)
+for p in range(nb):
+    row = crit[p]
+    if p + 1 < nb:
+        dd = np.diff(row) / GHZ / 1e3
+        tot += dd
+        if p < 4 or p % 8 == 0 or p >= nb - 3:
+            print("%5d  %8.2f  " % (p, (row[0] - t0) / GHZ / 1e3) + "  ".join("%-14.2f" % v for v in dd) + "  %.2f" % ((crit[p + 1, 0] - row[0]) / GHZ / 1e3))
+print("mean   %8s  " % "" + "  ".join("%-14.2f" % v for v in tot / (nb - 1)))
+print("critical path total %.1f us (first factor start -> last factor end)" % ((crit[nb - 1, 1] - t0) / GHZ / 1e3))
+started = jobs[:, 0] > 0
+print("jobs: %d of %d stamped; last job end %.1f us after start; median job duration %.1f us" % (
+    started.sum(), nj, (jobs[started, 1].max() - t0) / GHZ / 1e3, float(np.median((jobs[started, 1] - jobs[started, 0]))) / GHZ / 1e3))
