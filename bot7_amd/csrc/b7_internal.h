@@ -88,7 +88,7 @@ struct b7_ctx {
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
   bool diag_stamps = false, syrk_stamps = false;  // diagnostics: s_memtime phase stamps (B7_DIAG_STAMPS, B7_SYRK_STAMPS)
   bool mlp_scalar = false;                       // force the scalar basis-network kernel (B7_MLP_SCALAR)
-  int potrf_sched = 1;   // 1: one panel at a time (near update fused into the panel solve, far update riding on the
+  int potrf_sched = 3;   // 1: one panel at a time (near update fused into the panel solve, far update riding on the
                          // next diagonal-block launch) for Npad <= 4096, 2: always; 0: panel groups with separate
                          // update launches; 3: ONE persistent launch for Npad <= 2048, else as 1 (B7_POTRF_SCHED)
   int syrk_small = 1;    // whole-K single-stage kernel for trailing updates with <= 256 tiles (B7_SYRK_SMALL)

@@ -16,7 +16,8 @@
 //     which a job can finish).  A job owns its tile in REGISTERS from C_0 to the end: it waits for the two L tiles of
 //     the next panel update (flags), applies it, and after the last one waits for inv(L_JJ) and publishes L_IJ.  Tiles
 //     (p, p-1) and (p, p) are brought up to panel p-2 by a helper and handed to the critical workgroup.  The tiles of
-//     inv(L) are jobs of the same kind; the structurally zero upper tiles are filled by the last jobs of the queue.
+//     inv(L) are jobs of the same kind; the structurally zero upper tiles are filled by the first jobs of the queue,
+//     while the helpers would otherwise idle until the first panel is factored.
 //
 // Hand-offs follow cdna_hip_programming.md Guideline 16 in its write-through form: every byte another workgroup reads
 // inside the launch is stored with sc1 (buffer_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)), the
@@ -106,6 +107,38 @@ __device__ __forceinline__ bool wg_wait(unsigned *flag, const Flags &F, int *inf
   __syncthreads();
   const int ok = *sh_ok;
   __syncthreads();  // sh_ok may be rewritten by the next wait
+  return ok != 0;
+}
+
+// Two words at once (lanes 0 and 1 poll one each): the critical workgroup's two hand-overs cost one round trip.
+__device__ __forceinline__ bool wg_wait2(unsigned *f0, unsigned *f1, const Flags &F, int *info, int *sh_ok, int code) {
+  if (threadIdx.x < 64) {
+    unsigned *mine = (threadIdx.x & 1) ? f1 : f0;
+    int ok = 1;
+    unsigned spins = 0;
+    for (;;) {
+      const bool set = threadIdx.x > 1 || ld_flag(mine) != 0u;
+      if (__all(set)) break;
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 255u) == 0u && ld_flag(F.abort_word()) != 0u) {
+        ok = 0;
+        break;
+      }
+      if (spins > SPIN_LIMIT) {
+        if (threadIdx.x == 0) {
+          st_flag(F.abort_word(), (unsigned)code);
+          __hip_atomic_store(info + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = 0;
+        break;
+      }
+    }
+    if (threadIdx.x == 0) *sh_ok = ok;
+  }
+  __syncthreads();
+  const int ok = *sh_ok;
+  __syncthreads();
   return ok != 0;
 }
 
@@ -242,18 +275,16 @@ struct Prefetch {
     }
   }
   __device__ __forceinline__ void operator()(int kb, int wave) const {
-    if (kb != 2 || p + 1 >= a.nb) return;
+    // panel 0's neighbours come straight from K (cold in HBM: the blocking path after the factorisation is faster)
+    if (kb < 2 || p == 0 || p + 1 >= a.nb) return;
     const int n = a.n, lane = threadIdx.x & 63;
-    const bool fromK = p == 0;  // panel 0's neighbours have no earlier panel to wait for
     if (wave == 3) {
-      if (!fromK && ld_flag(F.pre_sub(p + 1)) == 0u) return;
-      const double *src = fromK ? a.K + (int64_t)NB * n : a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB;
-      rows(src, fromK, S1, 0, 64, p + 1, false);
+      if (done[0] != 0 || ld_flag(F.pre_sub(p + 1)) == 0u) return;
+      rows(a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, false, S1, 0, 64, p + 1, false);
       if (lane == 0) done[0] = 1;
     } else {
-      if (!fromK && ld_flag(F.pre_diag(p + 1)) == 0u) return;
-      const double *src = fromK ? a.K + (int64_t)NB * n + NB : a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB;
-      rows(src, fromK, S2, wave == 1 ? 0 : 32, 32, p + 1, true);
+      if (done[wave] != 0 || ld_flag(F.pre_diag(p + 1)) == 0u) return;
+      rows(a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB, false, S2, wave == 1 ? 0 : 32, 32, p + 1, true);
       if (lane == 0) done[wave] = 1;
     }
   }
@@ -273,6 +304,7 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
   unsigned long long *st = a.stamps;
 #define PST(p, i) \
   if (st && tid == 0) st[(p) * 8 + (i)] = __builtin_amdgcn_s_memtime()
+  PST(nb - 1, 6);  // entry (the last panel has no look-ahead: its slots 3..7 are free)
   {
     d2_t v[8];
     tile_load_plain(v, a.K, n);
@@ -292,25 +324,17 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     PST(p, 1);
     const bool last = p + 1 == nb;
     const bool have_d1 = pf_done[0] != 0, have_d2 = pf_done[1] != 0 && pf_done[2] != 0;
-    d2_t d1[8];
+    d2_t d1[8], d2[8];
     // what the prefetch did not get, first (its latency overlaps the stores of L_pp and inv(L_pp) issued behind it)
-    if (!last && !have_d1) {
-      if (p == 0) {
-        tile_load_plain(d1, a.K + (int64_t)NB * n, n);
-      } else {
-        if (!wg_wait(F.pre_sub(p + 1), F, a.info, sh_ok, 100 + p)) return;
-        tile_load_sc1(d1, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
-      }
-    }
-    d2_t d2[8];
-    if (!last && !have_d2) {
-      if (p == 0) {
-        tile_load_plain(d2, a.K + (int64_t)NB * n + NB, n);
-        add_extra(d2, 1, a.nreal, a.extra);
-      } else {
-        if (!wg_wait(F.pre_diag(p + 1), F, a.info, sh_ok, 200 + p)) return;
-        tile_load_sc1(d2, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB, n);
-      }
+    if (!last && p == 0) {
+      tile_load_plain(d1, a.K + (int64_t)NB * n, n);
+      tile_load_plain(d2, a.K + (int64_t)NB * n + NB, n);
+      add_extra(d2, 1, a.nreal, a.extra);
+    } else if (!last && (!have_d1 || !have_d2)) {
+      unsigned *f1 = F.pre_sub(p + 1), *f2 = F.pre_diag(p + 1);
+      if (!wg_wait2(have_d1 ? f2 : f1, have_d2 ? f1 : f2, F, a.info, sh_ok, 100 + p)) return;
+      if (!have_d1) tile_load_sc1(d1, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
+      if (!have_d2) tile_load_sc1(d2, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB, n);
     }
     PST(p, 2);
     {  // L_pp (upper triangle zeroed) and inv(L_pp), write-through
@@ -328,6 +352,7 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     }
     if (last) {
       wg_publish(F.ready(p, p));
+      PST(p, 7);  // exit
       break;
     }
     if (!have_d1) tile_to_lds(d1, S1);
@@ -338,15 +363,29 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     // L[p+1][p] = C inv(L_pp)': wave w rows 16 w .., all four column blocks; the chain of potrf_trsm_kernel<NEAR>
     // (k ascending, whole 16-blocks above the diagonal of inv(L_pp) skipped)
     d4_t lqv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    {
+      // operands of step t+1 are read from LDS while step t's MFMAs run (the compiler otherwise waits for each
+      // ds_read right in front of its MFMA: ~100 cycles per 64-cycle MFMA)
+      const double *ap = S1 + (wave * 16 + lr) * DLD + lq, *xp = X + lr * DLD + lq;
+      double aq = ap[0], xb[4];
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq)
+      for (int jb = 0; jb < 4; ++jb) xb[jb] = xp[jb * 16 * DLD];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int ko = kq * 16 + 4 * s4 + lq;
-        const double aq = S1[(wave * 16 + lr) * DLD + ko];
+      for (int t = 0; t < 16; ++t) {
+        const int kq = t >> 2;
+        double naq = 0.0, nxb[4] = {0.0, 0.0, 0.0, 0.0};
+        if (t + 1 < 16) {
+          naq = ap[4 * (t + 1)];
 #pragma unroll
-        for (int jb = kq; jb < 4; ++jb) lqv[jb] = mfma_f64(aq, X[(jb * 16 + lr) * DLD + ko], lqv[jb]);
+          for (int jb = (t + 1) >> 2; jb < 4; ++jb) nxb[jb] = xp[jb * 16 * DLD + 4 * (t + 1)];
+        }
+#pragma unroll
+        for (int jb = kq; jb < 4; ++jb) lqv[jb] = mfma_f64(aq, xb[jb], lqv[jb]);
+        aq = naq;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) xb[jb] = nxb[jb];
       }
+    }
     __syncthreads();  // every wave is done reading S1
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
@@ -365,26 +404,30 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     // C(p+1, p+1) -= L[p+1][p] L[p+1][p]': per 16x16 sub-tile the 64-deep chain from zero, then the subtraction
     // (syrk_tile / NEAR update); this wave's sub-tiles run as interleaved chains
     {
-      d4_t u[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      d4_t u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0}, u2 = {0.0, 0.0, 0.0, 0.0};
       const int nsub = SUB_N[wave];
+      const int s0 = SUB_S[wave][0], s1 = SUB_S[wave][1], s2 = SUB_S[wave][2];
+      const int c0 = SUB_C[wave][0], c1 = SUB_C[wave][1], c2 = SUB_C[wave][2];
+      const double *a0 = S1 + (16 * s0 + lr) * DLD + lq, *a1 = S1 + (16 * s1 + lr) * DLD + lq, *a2 = S1 + (16 * s2 + lr) * DLD + lq;
+      const double *b0 = S1 + (16 * c0 + lr) * DLD + lq, *b1 = S1 + (16 * c1 + lr) * DLD + lq, *b2 = S1 + (16 * c2 + lr) * DLD + lq;
+      double pa0 = a0[0], pa1 = a1[0], pa2 = a2[0], pb0 = b0[0], pb1 = b1[0], pb2 = b2[0];
 #pragma unroll
-      for (int k4 = 0; k4 < 16; ++k4) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          if (t < nsub)
-            u[t] = mfma_f64(S1[(16 * SUB_S[wave][t] + lr) * DLD + 4 * k4 + lq], S1[(16 * SUB_C[wave][t] + lr) * DLD + 4 * k4 + lq],
-                            u[t]);
+      for (int k4 = 0; k4 < 16; ++k4) {  // next step's operands in flight under this step's MFMAs
+        const int kn = k4 + 1 < 16 ? 4 * (k4 + 1) : 0;
+        const double na0 = a0[kn], na1 = a1[kn], na2 = a2[kn], nb0 = b0[kn], nb1 = b1[kn], nb2 = b2[kn];
+        u0 = mfma_f64(pa0, pb0, u0);
+        u1 = mfma_f64(pa1, pb1, u1);
+        u2 = mfma_f64(pa2, pb2, u2);  // waves 2 and 3: a spare chain, dropped below
+        pa0 = na0, pa1 = na1, pa2 = na2, pb0 = nb0, pb1 = nb1, pb2 = nb2;
       }
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-        if (t < nsub) {
-          const int s = SUB_S[wave][t], cb = SUB_C[wave][t];
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int e = (16 * s + lq + 4 * rr) * DLD + 16 * cb + lr;
-            A[e] = S2[e] - u[t][rr];
-          }
-        }
+      for (int rr = 0; rr < 4; ++rr) {
+        const int e0 = (16 * s0 + lq + 4 * rr) * DLD + 16 * c0 + lr, e1 = (16 * s1 + lq + 4 * rr) * DLD + 16 * c1 + lr,
+                  e2 = (16 * s2 + lq + 4 * rr) * DLD + 16 * c2 + lr;
+        A[e0] = S2[e0] - u0[rr];
+        A[e1] = S2[e1] - u1[rr];
+        if (nsub > 2) A[e2] = S2[e2] - u2[rr];
+      }
     }
     __syncthreads();
     put_identity_corner(A);
@@ -442,8 +485,8 @@ __device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J,
   }
   const int nupd = (type == JOB_PRE_DIAG) ? J - 1 : J;  // the critical workgroup applies panel J-1 to its own diagonal tile
   for (int q = 0; q < nupd; ++q) {
-    if (!wg_wait(F.ready(I, q), F, a.info, sh_ok, 1000 + I * 64 + q)) return false;
     if (I != J && !wg_wait(F.ready(J, q), F, a.info, sh_ok, 1000 + J * 64 + q)) return false;
+    if (!wg_wait(F.ready(I, q), F, a.info, sh_ok, 1000 + I * 64 + q)) return false;
     apply_update(C, a.L + ((int64_t)I * NB) * n + (int64_t)q * NB, a.L + ((int64_t)J * NB) * n + (int64_t)q * NB, n, sm);
   }
   double *Ai = sm, *Xp = sm + NB * DLD;
@@ -636,7 +679,7 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
       for (int p = 0; p < nb; ++p) jobs.push_back({JOB_INV_DIAG, p, p, p + 0.9});
     }
     for (int I = 0; I < nb; ++I)
-      for (int J = I + 1; J < nb; ++J) jobs.push_back({JOB_ZERO, I, J, 1e9});
+      for (int J = I + 1; J < nb; ++J) jobs.push_back({JOB_ZERO, I, J, -1.0});
     std::stable_sort(jobs.begin(), jobs.end(), [](const HostJob &x, const HostJob &y) { return x.key < y.key; });
     std::vector<int4> packed(jobs.size());
     for (size_t i = 0; i < jobs.size(); ++i) packed[i] = make_int4(jobs[i].type, jobs[i].I, jobs[i].J, 0);
@@ -696,3 +739,6 @@ extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_
                       hipMemcpyDeviceToHost));
   return B7_OK;
 }
+
+// diagnostics: persistent launches of this context that timed out on a hand-off and were redone by the launch schedule
+extern "C" int b7dbg_persist_aborts(b7_ctx *c) { return c ? c->persist_aborts : -1; }

@@ -1188,3 +1188,113 @@ def test_full_shape_cfg5(ctx, orc):
                                                                                  np.max(np.abs(ei - want))))
     assert wv > 1e-3, "EI at the winner should be O(1e-2 .. 1), not an underflow"
     assert idx == wi and val == pytest.approx(wv, rel=1e-6)
+
+
+# ---- the persistent Cholesky schedule (potrf_persist.hip): same bits as the launch schedule, also under load ----------
+def _two_schedules(monkeypatch):
+    import bot7_amd
+    out = []
+    for sched in ("1", "3"):
+        monkeypatch.setenv("B7_POTRF_SCHED", sched)
+        out.append(bot7_amd.Context(0))
+    monkeypatch.delenv("B7_POTRF_SCHED")
+    return out
+
+
+def _aborts(c):
+    from bot7_amd import _lib
+    return _lib.load().b7dbg_persist_aborts(c._h)
+
+
+@pytest.mark.parametrize("N,d,cols", [(2, 3, 1), (64, 6, 1), (100, 6, 1), (129, 6, 1), (256, 6, 7), (700, 32, 1),
+                                      (1024, 32, 1), (1500, 6, 1), (2048, 32, 1)])
+def test_persistent_cholesky_is_bit_identical_to_the_launch_schedule(orc, monkeypatch, N, d, cols):
+    """One persistent launch with flag hand-offs (default up to Npad = 2048) against two launches per panel: L, inv(L),
+    alpha and the likelihood must agree bit for bit -- only the schedule differs."""
+    launch, persist = _two_schedules(monkeypatch)
+    try:
+        obj = {3: lambda X: np.sin(3.0 * X).sum(axis=1, keepdims=True), 6: B.hartmann6, 32: B.ackley}[d]
+        X_obs, Y1, _, hyp = make_problem(None, orc, d, N, 64, obj)
+        Y = Y1 if cols == 1 else Y1 + 0.1 * np.random.default_rng(N).normal(size=(N, cols))
+        res = []
+        for c in (launch, persist):
+            r = c.gp_fit(X_obs, Y, want_nll=True, **hyp)
+            res.append(c.gp_download(N, cols) + (r["nll"], np.array([r["jitter"], r["info"]])))
+        for a, b in zip(*res):
+            assert np.array_equal(a, b)
+        f = orc.gp.fit(X_obs, Y, **hyp)
+        assert np.allclose(res[1][3], f.nll, rtol=1e-9, atol=1e-7)
+        assert _aborts(persist) == 0
+    finally:
+        launch.close()
+        persist.close()
+
+
+def test_persistent_cholesky_jitter_retries_and_plain_chol(orc, monkeypatch):
+    """The jitter schedule (eps on the diagonal of C_0 inside the persistent kernel) and b7_chol (no inverse)."""
+    launch, persist = _two_schedules(monkeypatch)
+    try:
+        X = orc.c.sobol(300, 4, 1)
+        X[17] = X[3]
+        X[250] = X[100]                                  # duplicates, no noise: singular K -> retries
+        Y = np.sin(3.0 * X).sum(axis=1, keepdims=True)
+        hyp = dict(lenscale_sq=np.full(4, 0.5), amp=1.0, noise=0.0, mean=0.0)
+        out = []
+        for c in (launch, persist):
+            r = c.gp_fit(X, Y, want_nll=True, **hyp)
+            out.append(c.gp_download(300) + (r["nll"], np.array([r["jitter"], r["info"]])))
+        assert out[0][4][0] > 0 and out[0][4][1] > 0
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+        rng = np.random.default_rng(2)
+        A = rng.normal(size=(333, 333))
+        S = A @ A.T + 333 * np.eye(333)
+        (L0, j0, i0), (L1, j1, i1) = launch.chol(S), persist.chol(S)
+        assert np.array_equal(L0, L1) and (j0, i0) == (j1, i1) == (0.0, 0)
+        assert np.allclose(L1 @ L1.T, S, rtol=1e-12, atol=1e-9)
+        assert _aborts(persist) == 0
+    finally:
+        launch.close()
+        persist.close()
+
+
+def test_persistent_cholesky_under_uneven_load(orc, monkeypatch):
+    """cdna_hip_programming.md Guideline 16: a hand-off protocol is tested under UNEVEN load.  While a second context keeps
+    the chip busy with posterior GEMMs of changing size, ten persistent fits in a row must reproduce the launch
+    schedule's bits every time (a stale or torn tile would change L; a stalled hand-off would time out into the
+    launch schedule, which is counted)."""
+    import threading
+    import bot7_amd
+    launch, persist = _two_schedules(monkeypatch)
+    noise_ctx = bot7_amd.Context(0)
+    try:
+        X_obs, Y, _, hyp = make_problem(None, orc, 32, 2048, 64, B.ackley)
+        launch.gp_fit(X_obs, Y, **hyp)
+        ref = launch.gp_download(2048)
+        Xn, Yn, _, hn = make_problem(None, orc, 6, 512, 64, B.hartmann6)
+        noise_ctx.gp_fit(Xn, Yn, **hn)
+        stop = threading.Event()
+
+        def load():
+            k = 0
+            while not stop.is_set():
+                noise_ctx.grid_sobol(20000 + 37000 * (k % 5), 6, 1, download=False)
+                noise_ctx.gp_predict(download=False)
+                k += 1
+            noise_ctx.sync()
+
+        th = threading.Thread(target=load)
+        th.start()
+        try:
+            for rep in range(10):
+                persist.gp_fit(X_obs, Y, **hyp)
+                got = persist.gp_download(2048)
+                for a, b in zip(ref, got):
+                    assert np.array_equal(a, b), "repetition %d differs" % rep
+        finally:
+            stop.set()
+            th.join()
+        print("persistent fits redone by the launch schedule under load:", _aborts(persist))
+    finally:
+        for c in (launch, persist, noise_ctx):
+            c.close()

@@ -44,6 +44,8 @@ for p in range(nb):
             print("%5d  %8.2f  " % (p, (row[0] - t0) / GHZ / 1e3) + "  ".join("%-14.2f" % v for v in dd) + "  %.2f" % ((crit[p + 1, 0] - row[0]) / GHZ / 1e3))
 print("mean   %8s  " % "" + "  ".join("%-14.2f" % v for v in tot / (nb - 1)))
 print("critical path total %.1f us (first factor start -> last factor end)" % ((crit[nb - 1, 1] - t0) / GHZ / 1e3))
+print("workgroup 0: entry -> first factor %.1f us; last factor end -> exit %.1f us; entry -> exit %.1f us" % (
+    (t0 - crit[nb - 1, 6]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 1]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 6]) / GHZ / 1e3))
 started = jobs[:, 0] > 0
 print("jobs: %d of %d stamped; last job end %.1f us after start; median job duration %.1f us" % (
     started.sum(), nj, (jobs[started, 1].max() - t0) / GHZ / 1e3, float(np.median((jobs[started, 1] - jobs[started, 0]))) / GHZ / 1e3))
