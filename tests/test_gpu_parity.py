@@ -1234,11 +1234,11 @@ def test_persistent_cholesky_jitter_retries_and_plain_chol(orc, monkeypatch):
     """The jitter schedule (eps on the diagonal of C_0 inside the persistent kernel) and b7_chol (no inverse)."""
     launch, persist = _two_schedules(monkeypatch)
     try:
-        X = orc.c.sobol(300, 4, 1)
-        X[17] = X[3]
+        X = orc.c.sobol(300, 3, 1)
+        X[7] = X[3]
         X[250] = X[100]                                  # duplicates, no noise: singular K -> retries
         Y = np.sin(3.0 * X).sum(axis=1, keepdims=True)
-        hyp = dict(lenscale_sq=np.full(4, 0.5), amp=1.0, noise=0.0, mean=0.0)
+        hyp = dict(lenscale_sq=np.full(3, 0.4), amp=1.0, noise=0.0, mean=0.0)
         out = []
         for c in (launch, persist):
             r = c.gp_fit(X, Y, want_nll=True, **hyp)
