@@ -172,7 +172,9 @@ void b7_destroy(b7_ctx *c) {
   (void)b7_comm_destroy(c);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pjobs, &c->pflags, &c->pstamps};
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pflags, &c->pstamps,
+                   &c->bhyp, &c->bw, &c->bzsc, &c->bzss, &c->bK, &c->bL, &c->bdinv, &c->bflags, &c->binfo, &c->bresid, &c->bterms};
+  for (auto &kv : c->pjobs_cache) b7_release(kv.second.buf);
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
     for (int i = 0; i < B7_MAX_TIMERS; ++i) {
@@ -489,6 +491,108 @@ int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_
   if (info_out) *info_out = info_first;
   if (c->potrf_sched_saved == 3 && c->persist_aborts < 3) c->potrf_sched = 3;
   c->fitted = true;
+  return B7_OK;
+}
+
+__global__ void __launch_bounds__(256) resid_batch_kernel(const double *__restrict__ y, double *__restrict__ r, int N,
+                                                          int Npad, const double *__restrict__ mean) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i < Npad) r[(int64_t)b * Npad + i] = i < N ? y[i] - mean[b] : 0.0;
+}
+
+int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *amp, const double *noise,
+                    const double *mean, double *nll_out, double *jitter_out, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "gp_nll_batch: call b7_gp_set_data first");
+  if (B < 1 || !lenscale_sq || !amp || !noise || !mean || !nll_out) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: bad arguments");
+  if (c->ycols != 1) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_nll_batch: one response column only");
+  if (c->Npad > 2048) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_nll_batch: N > 2048 (evaluate with b7_gp_fit_hyp one by one)");
+  const int N = c->N, n = c->Npad, d = c->dfit, dpad = c->dpad, nb = n / B7_PANEL;
+  for (int b = 0; b < B; ++b) {
+    for (int k = 0; k < d; ++k)
+      if (!(lenscale_sq[(size_t)b * d + k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: lenscale_sq[%d][%d] must be > 0", b, k);
+    if (!(amp[b] > 0.0) || !(noise[b] >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: amp > 0, noise >= 0 (fit %d)", b);
+  }
+  B7_HIP(c, hipSetDevice(c->device));
+  const size_t fw = persist_flag_words_host(nb), nn = (size_t)n * n;
+  B7_TRY(b7_ensure(c, c->bhyp, sizeof(double) * (size_t)B * (d + 3)));
+  B7_TRY(b7_ensure(c, c->bw, sizeof(double) * (size_t)B * dpad));
+  B7_TRY(b7_ensure(c, c->bzsc, sizeof(double) * (size_t)B * n * dpad));
+  B7_TRY(b7_ensure(c, c->bzss, sizeof(double) * (size_t)B * n));
+  B7_TRY(b7_ensure(c, c->bK, sizeof(double) * B * nn));
+  B7_TRY(b7_ensure(c, c->bL, sizeof(double) * B * nn));
+  B7_TRY(b7_ensure(c, c->bdinv, sizeof(double) * (size_t)B * n * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->bflags, sizeof(unsigned) * B * fw));
+  B7_TRY(b7_ensure(c, c->binfo, sizeof(int) * 4 * (size_t)B));
+  B7_TRY(b7_ensure(c, c->bresid, sizeof(double) * (size_t)B * n));
+  B7_TRY(b7_ensure(c, c->bterms, sizeof(double) * 2 * (size_t)B + 64));
+  // all hypers in one upload: [B x d lengthscales | B amp | B noise | B mean]
+  std::vector<double> pack((size_t)B * (d + 3));
+  memcpy(pack.data(), lenscale_sq, sizeof(double) * (size_t)B * d);
+  memcpy(pack.data() + (size_t)B * d, amp, sizeof(double) * B);
+  memcpy(pack.data() + (size_t)B * (d + 1), noise, sizeof(double) * B);
+  memcpy(pack.data() + (size_t)B * (d + 2), mean, sizeof(double) * B);
+  double *hyp_dev = (double *)c->bhyp.p;
+  B7_HIP(c, hipMemcpyAsync(hyp_dev, pack.data(), sizeof(double) * pack.size(), hipMemcpyHostToDevice, c->stream));
+  const double *ls_dev = hyp_dev, *amp_dev = hyp_dev + (size_t)B * d, *noise_dev = amp_dev + B, *mean_dev = noise_dev + B;
+  hipLaunchKernelGGL(resid_batch_kernel, dim3((n + 255) / 256, B), dim3(256), 0, c->stream, (const double *)c->ybuf.p,
+                     (double *)c->bresid.p, N, n, mean_dev);
+  B7_TRY(launch_kxx_batch(c, B, ls_dev, amp_dev, noise_dev, (double *)c->bw.p, (double *)c->bzsc.p, (double *)c->bzss.p,
+                          (double *)c->bK.p));
+  B7_TRY(launch_nll_batch(c, B, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bdinv.p, (unsigned *)c->bflags.p,
+                          (int *)c->binfo.p, (const double *)c->bresid.p, (double *)c->bterms.p, nullptr));
+  std::vector<int> info((size_t)B * 4);
+  std::vector<double> terms((size_t)B * 2);
+  B7_HIP(c, hipMemcpyAsync(info.data(), c->binfo.p, sizeof(int) * info.size(), hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipMemcpyAsync(terms.data(), c->bterms.p, sizeof(double) * terms.size(), hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));  // also: `pack` has been consumed
+  const double c0 = 0.5 * N * log(2.0 * M_PI);
+  for (int b = 0; b < B; ++b) {
+    double jitter = 0.0;
+    const int info_first = info[(size_t)b * 4];
+    int bad = info_first, aborted = info[(size_t)b * 4 + 1];
+    const double *Kb = (const double *)c->bK.p + b * nn;
+    double *Lb = (double *)c->bL.p + b * nn, *dib = (double *)c->bdinv.p + (size_t)b * n * B7_PANEL;
+    unsigned *fb = (unsigned *)c->bflags.p + b * fw;
+    int *ib = (int *)c->binfo.p + (size_t)b * 4;
+    const double *rb = (const double *)c->bresid.p + (size_t)b * n;
+    double *tb = (double *)c->bterms.p + 2 * (size_t)b;
+    auto redo = [&](double extra) -> int {  // this fit alone (it has the whole chip), eps on the diagonal
+      B7_TRY(launch_nll_one(c, Kb, Lb, dib, fb, ib, rb, tb, extra));
+      int two[2];
+      B7_HIP(c, hipMemcpyAsync(two, ib, sizeof(two), hipMemcpyDeviceToHost, c->stream));
+      B7_HIP(c, hipMemcpyAsync(&terms[(size_t)b * 2], tb, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+      bad = two[0];
+      aborted = two[1];
+      return B7_OK;
+    };
+    if (aborted) {  // a hand-off timed out (the chip was shared): once more, alone
+      c->persist_aborts += 1;
+      B7_TRY(redo(0.0));
+      if (aborted) return b7_fail(c, B7_ERR_HIP, "gp_nll_batch: hand-off time-out (code %d) in fit %d", aborted, b);
+    }
+    if (bad != 0) {  // the jitter schedule of utils/math.lua:174-202 for this fit
+      double *fro_dev = (double *)c->bterms.p + 2 * (size_t)B;
+      B7_TRY(launch_fro_norm_sq(c, Kb, N, n, fro_dev));
+      double fro = 0.0;
+      B7_HIP(c, hipMemcpyAsync(&fro, fro_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+      const double max_eps = sqrt(fro);
+      if (max_eps != max_eps) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: K of fit %d contains NaN", b);
+      double eps = c->opts.jitter_eps;
+      while (bad != 0) {
+        if (eps > max_eps) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: fit %d cannot be factored", b);
+        eps = eps * c->opts.jitter_growth;
+        B7_TRY(redo(eps));
+        if (aborted) return b7_fail(c, B7_ERR_HIP, "gp_nll_batch: hand-off time-out (code %d) in fit %d", aborted, b);
+        jitter = eps;
+      }
+    }
+    nll_out[b] = 0.5 * terms[(size_t)b * 2] + terms[(size_t)b * 2 + 1] + c0;
+    if (jitter_out) jitter_out[b] = jitter;
+    if (info_out) info_out[b] = info_first;
+  }
   return B7_OK;
 }
 

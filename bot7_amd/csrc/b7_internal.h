@@ -99,10 +99,13 @@ struct b7_ctx {
   int post_variant = 9;  // posterior.hip launch_post: 9 = 128x256 tile, 8 waves, odd LDS stride, zero-strip skip, static
                          // priority raise for the younger half of the waves (B7_POST_VARIANT overrides)
   // ---- persistent Cholesky schedule (potrf_persist.hip)
-  DevBuf pjobs;    // the job queue of the current (nb, with_inverse) shape
+  struct JobList { DevBuf buf; int n = 0; };
+  std::map<int, JobList> pjobs_cache;  // job queues by (nb, mode)
   DevBuf pflags;   // hand-off flags, zeroed ahead of every launch
   DevBuf pstamps;  // diagnostics (B7_PERSIST_STAMPS)
-  int pjobs_nb = 0, pjobs_inv = -1, pjobs_n = 0;
+  int pjobs_nb = 0, pjobs_n = 0;   // shape of the last single persistent launch (for the stamp reader)
+  // b7_gp_nll_batch: B fits of the resident data in likelihood mode
+  DevBuf bhyp, bw, bzsc, bzss, bK, bL, bdinv, bflags, binfo, bresid, bterms;
   bool persist_attr_set = false, persist_stamps = false;
   int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
@@ -175,16 +178,24 @@ int launch_remove_rows(b7_ctx *c, const double *src, double *dst, int64_t M, int
 int launch_gather_rows(b7_ctx *c, const double *src, double *out, const int64_t *idx0_dev, int64_t n, int d);
 
 // covar.hip
+struct KBatchDesc {   // a batch of fits over the same observations: strides (doubles) per fit, per-fit amplitudes
+  int64_t s_w = 0, s_zsc = 0, s_zsh = 0, s_out = 0;
+  const double *amp = nullptr;
+};
 struct ObsSet {
   const double *zsc;  // npad x dpad scaled observations
   const double *zsh;  // npad half norms (+inf in the padding)
   int npad;
+  const double *w = nullptr;  // inverse squared lengthscales (dpad); null = the context's current ones
+  KBatchDesc batch;
 };
 int launch_prep_obs_aux(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int npad, double *zsc,
                         double *zsh);
 int launch_k_generic(b7_ctx *c, const double *xq, int64_t rows, int64_t Mtotal, const ObsSet &o, double *out);
 int launch_prep_obs(b7_ctx *c, const double *xobs, const double *lenscale_sq_dev, int N, int d);
 int launch_kxx(b7_ctx *c, double diag_add);
+int launch_kxx_batch(b7_ctx *c, int B, const double *ls_dev, const double *amp_dev, const double *noise_dev, double *w,
+                     double *zsc, double *zss, double *K);
 int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
                double *mu, int ycols);
 
@@ -192,6 +203,11 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
 int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I -> L, dinv, info (+ Linv, using W)
 int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
 int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse);  // the same in one persistent launch (Npad <= 2048)
+int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv, unsigned *flags, int *info,
+                     const double *resid, double *terms, const double *unused);
+int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned *flags, int *info, const double *resid,
+                   double *terms, double extra);
+size_t persist_flag_words_host(int nb);
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 int launch_nll_terms(b7_ctx *c, double *out_dev);  // out[0] = sum log L_ii, out[1 + k] = r_k' alpha_k
 int launch_fro_norm_sq(b7_ctx *c, const double *A, int n, int ld, double *out_dev);  // sum of squares of A[0:n, 0:n]

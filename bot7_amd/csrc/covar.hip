@@ -30,10 +30,16 @@ namespace {
 // One wave per 64 observations: the rows are loaded and stored through an LDS tile (coalesced both ways; a thread
 // walking its own row in global memory was 16 us at N = 2048), the weights 1/ls are formed once per workgroup, and
 // each lane sums its row in ascending k exactly as before (same bits).
-__global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__ xobs, const double *__restrict__ ls,
-                                                      double *__restrict__ w, double *__restrict__ zsc,
-                                                      double *__restrict__ zsh, int N, int Npad, int d, int dpad) {
+__global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__ xobs, const double *ls, double *w,
+                                                      double *zsc, double *zsh, int N, int Npad, int d, int dpad) {
   extern __shared__ __align__(16) double psm[];
+  {  // batch of fits over the same observations (b7_gp_nll_batch): blockIdx.y selects the hyper vector
+    const int64_t b = blockIdx.y;
+    ls += b * d;
+    w += b * dpad;
+    zsc += b * (int64_t)Npad * dpad;
+    zsh += b * Npad;
+  }
   const int tld = dpad + 1, lane = threadIdx.x, row0 = blockIdx.x * 64;
   double *tile = psm, *wl = psm + 64 * tld;
   for (int k = lane; k < dpad; k += 64) {
@@ -109,13 +115,22 @@ __host__ __device__ constexpr int ksx_slab(int dpad) { return dpad >= 48 ? 32 : 
 // DPAD = padded input dimension, one of the classes {4, 8, 16, 32, 48, 64, 96} (b7_dpad_class): compile-time so that
 // the MFMA chain over DPAD/4 k-steps unrolls and the query fragments stay in registers for the whole block.
 // ABLATE (diagnostic, B7_KSX_ABLATE): 0 = product; 1 = no stores; 2 = no exp; 3 = no MFMA.
+// blockIdx.z = fit index of a batch over the same observations (b7_gp_nll_batch); all zero / null for a single fit
+using KBatch = KBatchDesc;
 template <int DPAD, int ABLATE>
 __global__ void __launch_bounds__(256)
-    ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad_rt,
-               const double *__restrict__ w, const double *__restrict__ zsc, const double *__restrict__ zsh,
-               const double *__restrict__ alpha, double amp, double meanc, int Npad, double *__restrict__ out,
-               double *__restrict__ mu) {
+    ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad_rt, const double *w,
+               const double *zsc, const double *zsh, const double *__restrict__ alpha, double amp, double meanc, int Npad,
+               double *out, double *__restrict__ mu, KBatch kb) {
   extern __shared__ __align__(16) double sm[];
+  if (kb.amp) {
+    const int64_t bz = blockIdx.z;
+    w += bz * kb.s_w;
+    zsc += bz * kb.s_zsc;
+    zsh += bz * kb.s_zsh;
+    out += bz * kb.s_out;
+    amp = kb.amp[bz];
+  }
   constexpr int KO = ksx_slab(DPAD);
   constexpr int TPR = 256 / KO;                       // staging threads per slab row
   constexpr int dpad = DPAD, NCH = (DPAD / 2 + TPR - 1) / TPR, KSTEPS = DPAD / 4;
@@ -261,7 +276,11 @@ __global__ void __launch_bounds__(256)
 
 // K(X,X) post-pass: padding rows/columns become identity, `diag_add` (noise) goes on the diagonal.
 __global__ void __launch_bounds__(256)
-    kxx_fix_kernel(double *__restrict__ K, int N, int Npad, double diag_add) {
+    kxx_fix_kernel(double *K, int N, int Npad, double diag_add, const double *diag_arr, int64_t sK) {
+  if (diag_arr) {  // batch: blockIdx.y = fit index
+    K += (int64_t)blockIdx.y * sK;
+    diag_add = diag_arr[blockIdx.y];
+  }
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)Npad * Npad) return;
   int i = (int)(e / Npad), j = (int)(e - (int64_t)i * Npad);
@@ -287,8 +306,8 @@ int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mto
   // dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup)
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad, (const double *)c->w.p,
-                     o.zsc, o.zsh, alpha, c->amp, meanc, o.npad, out, mu);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, xq, row0, Mtotal, d, c->dpad, o.w ? o.w : (const double *)c->w.p,
+                     o.zsc, o.zsh, alpha, c->amp, meanc, o.npad, out, mu, o.batch);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -355,7 +374,31 @@ int launch_kxx(b7_ctx *c, double diag_add) {
                       (double *)c->K.p, nullptr));
   int64_t total = (int64_t)Npad * Npad;
   hipLaunchKernelGGL(kxx_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (double *)c->K.p,
-                     c->N, Npad, diag_add);
+                     c->N, Npad, diag_add, (const double *)nullptr, (int64_t)0);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+// ---- B fits over the same observations: per-fit scaled observations, then K_b = amp_b exp(-D_b / 2) + noise_b I ---------
+// ls: B x d, amp / noise: B (device).  zsc: B x Npad x dpad, zss: B x Npad, w: B x dpad, K: B x Npad x Npad.
+int launch_kxx_batch(b7_ctx *c, int B, const double *ls_dev, const double *amp_dev, const double *noise_dev, double *w,
+                     double *zsc, double *zss, double *K) {
+  PhaseScope ps(c, "kxx");
+  const int Npad = c->Npad, d = c->dfit, dpad = c->dpad;
+  const size_t lds = sizeof(double) * (64 * (size_t)(dpad + 1) + dpad);
+  hipLaunchKernelGGL(prep_obs_kernel, dim3((Npad + 63) / 64, B), dim3(64), lds, c->stream, (const double *)c->xobs.p, ls_dev,
+                     w, zsc, zss, c->N, Npad, d, dpad);
+  ObsSet o{zsc, zss, Npad};
+  o.w = w;
+  o.batch.s_w = dpad;
+  o.batch.s_zsc = (int64_t)Npad * dpad;
+  o.batch.s_zsh = Npad;
+  o.batch.s_out = (int64_t)Npad * Npad;
+  o.batch.amp = amp_dev;
+  B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, 1, B), (const double *)c->xobs.p, 0, c->N, d, o, nullptr, 0.0, K, nullptr));
+  const int64_t total = (int64_t)Npad * Npad;
+  hipLaunchKernelGGL(kxx_fix_kernel, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, c->stream, K, c->N, Npad, 0.0,
+                     noise_dev, total);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

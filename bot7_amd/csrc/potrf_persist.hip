@@ -52,7 +52,7 @@ constexpr unsigned SPIN_LIMIT = 1u << 21;    // polls before a waiter gives up (
 constexpr int PERSIST_LDS_BYTES = (4 * NB * DLD + 32 * TLD) * 8;  // A, X, T, S1, S2 of the critical workgroup: 141 KiB
 static_assert(PERSIST_LDS_BYTES >= 2 * GT::STAGE_DOUBLES * 4 && PERSIST_LDS_BYTES > 80 * 1024, "one workgroup per CU");
 
-enum JobType { JOB_TILE = 0, JOB_PRE_SUB = 1, JOB_PRE_DIAG = 2, JOB_INV = 3, JOB_INV_DIAG = 4, JOB_ZERO = 5 };
+enum JobType { JOB_TILE = 0, JOB_PRE_SUB = 1, JOB_PRE_DIAG = 2, JOB_INV = 3, JOB_INV_DIAG = 4, JOB_ZERO = 5, JOB_VEC = 6 };
 
 struct PArgs {
   const double *K;
@@ -63,6 +63,13 @@ struct PArgs {
   const int4 *jobs;
   int njobs, n, nb, nreal, with_inverse;
   double extra;
+  // a batch of independent factorisations in one launch (blockIdx.y = fit): strides per fit, 0 for a single one
+  int64_t sK, sL, sdinv;
+  int sflags, sinfo;
+  // likelihood mode (b7_gp_nll_batch): no inverse; one JOB_VEC per fit solves L z = r alongside and leaves
+  // terms[0] = |z|^2, terms[1] = sum log L_ii
+  const double *resid;
+  double *terms;
 };
 
 // ---- flags ---------------------------------------------------------------------------------------------------------
@@ -608,9 +615,86 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
   return true;
 }
 
+// L z = r by forward substitution, block row by block row as the tiles of L are published; |z|^2 and sum log L_ii are
+// all the likelihood needs (no inverse, no alpha).  One workgroup per fit; thread t: row t >> 2, a quarter of the columns.
+__device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok) {
+  const int n = a.n, nb = a.nb, tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+  double *z = sm, *accs = sm + 64 * 64, *red = accs + 64;
+  double ssq = 0.0, logdet = 0.0;
+  for (int p = 0; p < nb; ++p) {
+    double acc = 0.0;
+    for (int q = 0; q < p; ++q) {
+      if (!wg_wait(F.ready(p, q), F, a.info, sh_ok, 50000 + p * 64 + q)) return false;
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(a.L + ((int64_t)p * NB) * n + (int64_t)q * NB);
+      d2_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ld16_sc1(rs, (row * n + 16 * part + 2 * i) * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc += v[i][0] * z[q * 64 + 16 * part + 2 * i];
+        acc += v[i][1] * z[q * 64 + 16 * part + 2 * i + 1];
+      }
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0) accs[row] = a.resid[p * 64 + row] - acc;
+    if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, 60000 + p)) return false;  // its barrier publishes accs
+    const __amdgpu_buffer_rsrc_t rd = tile_rsrc(a.dinv + (int64_t)p * NB * NB);
+    double sz = 0.0;
+    {
+      d2_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ld16_sc1(rd, (row * NB + 16 * part + 2 * i) * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sz += v[i][0] * accs[16 * part + 2 * i];
+        sz += v[i][1] * accs[16 * part + 2 * i + 1];
+      }
+    }
+    sz += __shfl_xor(sz, 1);
+    sz += __shfl_xor(sz, 2);
+    if (part == 0) {
+      z[p * 64 + row] = sz;
+      ssq += sz * sz;
+      const unsigned long long bits = __hip_atomic_load(
+          reinterpret_cast<const unsigned long long *>(a.L + ((int64_t)p * NB + row) * n + (int64_t)p * NB + row),
+          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      logdet += log(__longlong_as_double((long long)bits));
+    }
+    __syncthreads();
+  }
+  red[tid] = part == 0 ? ssq : 0.0;
+  red[256 + tid] = part == 0 ? logdet : 0.0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[tid] += red[tid + o];
+      red[256 + tid] += red[256 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.terms[0] = red[0];
+    a.terms[1] = red[256];
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
   extern __shared__ __align__(16) double dsm[];
   __shared__ int sh_ok, sh_job, pf_done[4];
+  {
+    const int64_t b = blockIdx.y;  // one factorisation per grid row
+    a.K += b * a.sK;
+    a.L += b * a.sL;
+    a.dinv += b * a.sdinv;
+    a.flags += b * a.sflags;
+    a.info += b * a.sinfo;
+    if (a.resid) {
+      a.resid += b * a.n;
+      a.terms += 2 * b;
+    }
+  }
   const Flags F{a.flags, a.nb};
   if (blockIdx.x == 0) {
     critical_path(a, F, dsm, &sh_ok, pf_done);
@@ -634,6 +718,8 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
       ok = tile_job(a, F, type, I, J, dsm, &sh_ok);
     } else if (type == JOB_INV) {
       ok = inv_job(a, F, I, J, dsm, &sh_ok);
+    } else if (type == JOB_VEC) {
+      ok = vec_job(a, F, dsm, &sh_ok);
     } else if (type == JOB_INV_DIAG) {  // inv(L)[p][p] = inv(L_pp): nobody inside the launch reads it
       ok = wg_wait(F.ready(I, I), F, a.info, &sh_ok, 40000 + I);
       if (ok) {
@@ -660,12 +746,11 @@ struct HostJob {
 
 }  // namespace
 
-// K + extra*I -> L, dinv, info (+ Linv) in one persistent launch.  The caller has checked Npad <= 2048.
-int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
-  PhaseScope ps(c, "potrf");
-  const int n = c->Npad, nb = n / NB;
-  c->linv_done = false;
-  if (c->pjobs_nb != nb || c->pjobs_inv != (with_inverse ? 1 : 0)) {
+// mode 0: L, dinv; 1: + inv(L); 2: likelihood terms only (JOB_VEC), no inverse and no zero fill
+static int persist_jobs(b7_ctx *c, int nb, int mode, const int4 **jobs_dev, int *njobs) {
+  const int key = nb * 4 + mode;
+  auto it = c->pjobs_cache.find(key);
+  if (it == c->pjobs_cache.end()) {
     // the queue: sorted by the panel at whose end a job can finish; every dependency of a job is produced by workgroup 0
     // or sits earlier in this order
     std::vector<HostJob> jobs;
@@ -673,60 +758,148 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
       for (int I = J + 2; I < nb; ++I) jobs.push_back({JOB_TILE, I, J, J + 0.001 * (I - J)});
     for (int p = 2; p < nb; ++p) jobs.push_back({JOB_PRE_SUB, p, p - 1, (p - 1) - 0.6});
     for (int p = 2; p < nb; ++p) jobs.push_back({JOB_PRE_DIAG, p, p, (p - 1) - 0.55});
-    if (with_inverse) {
+    if (mode == 1) {
       for (int p = 1; p < nb; ++p)
         for (int j = 0; j < p; ++j) jobs.push_back({JOB_INV, p, j, p + 0.5 + 0.001 * (p - j)});
       for (int p = 0; p < nb; ++p) jobs.push_back({JOB_INV_DIAG, p, p, p + 0.9});
     }
-    for (int I = 0; I < nb; ++I)
-      for (int J = I + 1; J < nb; ++J) jobs.push_back({JOB_ZERO, I, J, -1.0});
+    if (mode == 2) {
+      jobs.push_back({JOB_VEC, 0, 0, -2.0});  // first: it is resident from the start and follows the panels
+    } else {
+      for (int I = 0; I < nb; ++I)
+        for (int J = I + 1; J < nb; ++J) jobs.push_back({JOB_ZERO, I, J, -1.0});
+    }
     std::stable_sort(jobs.begin(), jobs.end(), [](const HostJob &x, const HostJob &y) { return x.key < y.key; });
     std::vector<int4> packed(jobs.size());
     for (size_t i = 0; i < jobs.size(); ++i) packed[i] = make_int4(jobs[i].type, jobs[i].I, jobs[i].J, 0);
-    B7_TRY(b7_ensure(c, c->pjobs, sizeof(int4) * (packed.size() + 1)));
-    B7_HIP(c, hipMemcpy(c->pjobs.p, packed.data(), sizeof(int4) * packed.size(), hipMemcpyHostToDevice));
-    c->pjobs_n = (int)packed.size();
-    c->pjobs_nb = nb;
-    c->pjobs_inv = with_inverse ? 1 : 0;
+    b7_ctx::JobList jl;
+    B7_TRY(b7_ensure(c, jl.buf, sizeof(int4) * (packed.size() + 1)));
+    B7_HIP(c, hipMemcpy(jl.buf.p, packed.data(), sizeof(int4) * packed.size(), hipMemcpyHostToDevice));
+    jl.n = (int)packed.size();
+    it = c->pjobs_cache.emplace(key, jl).first;
   }
-  const size_t flag_words = (size_t)round_up(FLAG_HDR + 2 * nb * nb + 2 * nb, 4);
-  B7_TRY(b7_ensure(c, c->pflags, sizeof(unsigned) * flag_words));
+  *jobs_dev = (const int4 *)it->second.buf.p;
+  *njobs = it->second.n;
+  return B7_OK;
+}
+
+static size_t persist_flag_words(int nb) { return (size_t)round_up(FLAG_HDR + 2 * nb * nb + 2 * nb, 4); }
+
+// B independent factorisations of n x n matrices (strides in PArgs) in ONE launch: grid (1 + helpers, B).  Flags and
+// info of all B fits are zeroed here.  The caller guarantees B * (1 + helpers) <= CUs (every workgroup resident).
+static int persist_launch(b7_ctx *c, PArgs a, int B, int mode, int helpers) {
   if (!c->persist_attr_set) {
     B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_persist_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS_BYTES));
     c->persist_attr_set = true;
   }
-  B7_HIP(c, hipMemsetAsync(c->pflags.p, 0, sizeof(unsigned) * flag_words, c->stream));
-  B7_HIP(c, hipMemsetAsync(c->info.p, 0, 4 * sizeof(int), c->stream));
-  PArgs a;
+  B7_TRY(persist_jobs(c, a.nb, mode, &a.jobs, &a.njobs));
+  B7_HIP(c, hipMemsetAsync(a.flags, 0, sizeof(unsigned) * (B > 1 ? (size_t)a.sflags * B : persist_flag_words(a.nb)), c->stream));
+  B7_HIP(c, hipMemsetAsync(a.info, 0, sizeof(int) * (B > 1 ? (size_t)a.sinfo * B : 4), c->stream));
+  a.with_inverse = mode == 1 ? 1 : 0;
+  hipLaunchKernelGGL(potrf_persist_kernel, dim3(1 + helpers, B), dim3(256), PERSIST_LDS_BYTES, c->stream, a);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+// K + extra*I -> L, dinv, info (+ Linv) in one persistent launch.  The caller has checked Npad <= 2048.
+int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
+  PhaseScope ps(c, "potrf");
+  const int n = c->Npad, nb = n / NB, mode = with_inverse ? 1 : 0;
+  c->linv_done = false;
+  B7_TRY(b7_ensure(c, c->pflags, sizeof(unsigned) * persist_flag_words(nb)));
+  PArgs a = {};
   a.K = (const double *)c->K.p;
   a.L = (double *)c->L.p;
   a.Linv = with_inverse ? (double *)c->Linv.p : nullptr;
   a.dinv = (double *)c->dinv.p;
   a.flags = (unsigned *)c->pflags.p;
   a.info = (int *)c->info.p;
-  a.stamps = nullptr;
-  if (c->persist_stamps) {
-    B7_TRY(b7_ensure(c, c->pstamps, sizeof(unsigned long long) * ((size_t)nb * 8 + (size_t)c->pjobs_n * 2)));
-    B7_HIP(c, hipMemsetAsync(c->pstamps.p, 0, sizeof(unsigned long long) * ((size_t)nb * 8 + (size_t)c->pjobs_n * 2),
-                             c->stream));
-    a.stamps = (unsigned long long *)c->pstamps.p;
-  }
-  a.jobs = (const int4 *)c->pjobs.p;
-  a.njobs = c->pjobs_n;
   a.n = n;
   a.nb = nb;
   a.nreal = c->N;
-  a.with_inverse = with_inverse ? 1 : 0;
   a.extra = extra;
+  const int4 *jobs = nullptr;
+  int njobs = 0;
+  B7_TRY(persist_jobs(c, nb, mode, &jobs, &njobs));
+  c->pjobs_nb = nb;
+  c->pjobs_n = njobs;
+  if (c->persist_stamps) {
+    const size_t words = (size_t)nb * 8 + (size_t)njobs * 2;
+    B7_TRY(b7_ensure(c, c->pstamps, sizeof(unsigned long long) * words));
+    B7_HIP(c, hipMemsetAsync(c->pstamps.p, 0, sizeof(unsigned long long) * words, c->stream));
+    a.stamps = (unsigned long long *)c->pstamps.p;
+  }
   // one workgroup per CU (the LDS request guarantees it); all of them must be resident at once, so never more than CUs
-  int helpers = c->pjobs_n < c->cus - 1 ? c->pjobs_n : c->cus - 1;
+  int helpers = njobs < c->cus - 1 ? njobs : c->cus - 1;
   if (c->persist_helpers > 0 && c->persist_helpers < helpers) helpers = c->persist_helpers;
-  hipLaunchKernelGGL(potrf_persist_kernel, dim3(1 + helpers), dim3(256), PERSIST_LDS_BYTES, c->stream, a);
-  B7_HIP(c, hipGetLastError());
+  B7_TRY(persist_launch(c, a, 1, mode, helpers));
   c->linv_done = with_inverse;
   return B7_OK;
 }
+
+// B likelihood evaluations of the resident data set under B hyper vectors (b7_gp_nll_batch): per fit the factorisation and
+// L z = r in likelihood mode, as many fits per launch as fit on the chip, launches back to back.
+// K: B x n x n assembled matrices; L, dinv, flags, info: scratch per fit; resid: B x n; terms: B x 2.
+int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv, unsigned *flags, int *info,
+                     const double *resid, double *terms, const double *extra_per_fit_unused) {
+  (void)extra_per_fit_unused;
+  PhaseScope ps(c, "potrf");
+  const int n = c->Npad, nb = n / NB;
+  const int4 *jobs = nullptr;
+  int njobs = 0;
+  B7_TRY(persist_jobs(c, nb, 2, &jobs, &njobs));
+  const int helpers = njobs < c->cus - 1 ? njobs : c->cus - 1;
+  const int per_launch = c->cus / (1 + helpers) > 0 ? c->cus / (1 + helpers) : 1;
+  const int64_t nn = (int64_t)n * n;
+  const int fw = (int)persist_flag_words(nb);
+  for (int b0 = 0; b0 < B; b0 += per_launch) {
+    const int nb_here = B - b0 < per_launch ? B - b0 : per_launch;
+    PArgs a = {};
+    a.K = K + b0 * nn;
+    a.L = L + b0 * nn;
+    a.dinv = dinv + (int64_t)b0 * n * NB;
+    a.flags = flags + (int64_t)b0 * fw;
+    a.info = info + b0 * 4;
+    a.n = n;
+    a.nb = nb;
+    a.nreal = c->N;
+    a.extra = 0.0;
+    a.sK = nn;
+    a.sL = nn;
+    a.sdinv = (int64_t)n * NB;
+    a.sflags = fw;
+    a.sinfo = 4;
+    a.resid = resid + (int64_t)b0 * n;
+    a.terms = terms + 2 * b0;
+    B7_TRY(persist_launch(c, a, nb_here, 2, helpers));
+  }
+  return B7_OK;
+}
+
+// one fit of the batch again with eps on the diagonal (the jitter schedule of a fit whose plain attempt failed)
+int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned *flags, int *info, const double *resid,
+                   double *terms, double extra) {
+  const int n = c->Npad, nb = n / NB;
+  const int4 *jobs = nullptr;
+  int njobs = 0;
+  B7_TRY(persist_jobs(c, nb, 2, &jobs, &njobs));
+  PArgs a = {};
+  a.K = K;
+  a.L = L;
+  a.dinv = dinv;
+  a.flags = flags;
+  a.info = info;
+  a.n = n;
+  a.nb = nb;
+  a.nreal = c->N;
+  a.extra = extra;
+  a.resid = resid;
+  a.terms = terms;
+  return persist_launch(c, a, 1, 2, njobs < c->cus - 1 ? njobs : c->cus - 1);
+}
+
+size_t persist_flag_words_host(int nb) { return persist_flag_words(nb); }
 
 // diagnostics (tools/persist_stamps.py): the stamps of the last persistent launch, [nb][8] then [njobs][2]
 extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_words, int *nb_out, int *njobs_out) {

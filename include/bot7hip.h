@@ -129,6 +129,16 @@ int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int 
 int b7_gp_set_data(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols);
 int b7_gp_fit_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info);
 
+/* B likelihood evaluations of the resident data at once: the slice sampler's step-out / step-in probes
+ * (samplers/slice.lua:118-164) and multi-chain samplers ask for the density at several hyper vectors per update.
+ * lenscale_sq is B x d row-major; amp / noise / mean have B entries; nll_out[B] as b7_gp_fit_hyp's (same jitter schedule
+ * per fit: jitter_out[B] / info_out[B], nullable).  The B factorisations run concurrently in ONE persistent launch (each
+ * a chain of workgroups; 28 fit on the chip at N <= 256, 7 at N <= 512, larger ones go one after the other), with L z = r
+ * solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched.
+ * One response column, N <= 2048. */
+int b7_gp_nll_batch(b7_ctx *ctx, int B, const double *lenscale_sq, const double *amp, const double *noise,
+                    const double *mean, double *nll_out, double *jitter_out, int *info_out);
+
 /* utils.math.chol(src, 'L') (utils/math.lua:159-218) on a caller-provided symmetric n x n matrix: lower factor
  * with the same jitter schedule as b7_gp_fit.  res_host n x n (upper triangle zero).  Replaces the current fit
  * on this context.  jitter_used / info as in b7_gp_fit (nullable). */

@@ -1298,3 +1298,78 @@ def test_persistent_cholesky_under_uneven_load(orc, monkeypatch):
     finally:
         for c in (launch, persist, noise_ctx):
             c.close()
+
+
+# ---- batched likelihoods for the sampler (VERDICT r1 #4) ----------------------------------------------------------------
+@pytest.mark.parametrize("d,N,B", [(6, 256, 16), (6, 100, 5), (32, 500, 9), (6, 1100, 3)])
+def test_nll_batch_matches_single_fits_and_oracle(ctx, orc, d, N, B):
+    """b7_gp_nll_batch: B hyper vectors, one persistent launch (or a few), each NLL against b7_gp_fit_hyp and the oracle to
+    1e-9; the context's current fit is left alone."""
+    obj = B_OBJ[d]
+    X_obs, Y, X_hid, hyp = make_problem(None, orc, d, N, 300, obj)
+    ctx.gp_fit(X_obs, Y, **hyp)                       # the current fit, with predictions
+    ctx.grid_upload(X_hid)
+    mu0, var0 = ctx.gp_predict()
+    rng = np.random.default_rng(B)
+    ls = hyp["lenscale_sq"] * np.exp(rng.normal(scale=0.5, size=(B, d)))
+    amp = hyp["amp"] * np.exp(rng.normal(scale=0.3, size=B))
+    noise = hyp["noise"] * np.exp(rng.normal(scale=1.0, size=B))
+    mean = hyp["mean"] + rng.normal(scale=0.1, size=B)
+    nll, jit, info = ctx.gp_nll_batch(ls, amp, noise, mean, want_info=True)
+    assert (jit == 0).all() and (info == 0).all()
+    mu1, var1 = ctx.gp_predict()
+    assert np.array_equal(mu0, mu1) and np.array_equal(var0, var1)      # untouched
+    for b in range(B):
+        f = orc.gp.fit(X_obs, Y, ls[b], amp[b], noise[b], mean[b])
+        assert nll[b] == pytest.approx(float(f.nll[0]), rel=1e-9, abs=1e-7)
+    single = np.array([ctx.gp_fit_hyp(ls[b], amp[b], noise[b], mean[b], want_nll=True)["nll"][0] for b in range(B)])
+    assert np.allclose(nll, single, rtol=1e-11, atol=1e-9)
+
+
+B_OBJ = {6: B.hartmann6, 32: B.ackley}
+
+
+def test_nll_batch_jitter_and_errors(ctx, orc):
+    import bot7_amd
+    X = orc.c.sobol(200, 3, 1)
+    X[7] = X[3]
+    Y = np.sin(3.0 * X).sum(axis=1, keepdims=True)
+    ctx.gp_set_data(X, Y)
+    ls = np.tile(np.full(3, 0.4), (3, 1))
+    nll, jit, info = ctx.gp_nll_batch(ls, [1.0, 1.0, 1.0], [0.0, 1e-3, 0.0], [0.0, 0.0, 0.1], want_info=True)
+    for b in range(3):
+        r = ctx.gp_fit_hyp(ls[b], 1.0, [0.0, 1e-3, 0.0][b], [0.0, 0.0, 0.1][b], want_nll=True)
+        assert jit[b] == r["jitter"] and info[b] == r["info"]
+        assert nll[b] == pytest.approx(float(r["nll"][0]), rel=1e-9, abs=1e-7)
+    assert jit[0] > 0 and jit[1] == 0 and jit[2] > 0
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.gp_nll_batch(ls, [1.0, -1.0, 1.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0])
+    ctx.gp_set_data(X, np.hstack([Y, Y]))
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        ctx.gp_nll_batch(ls, 1.0, 1e-3, 0.0)
+    assert e.value.code == -5
+
+
+def test_nll_batch_sixteen_fits_cost_less_than_two(ctx, orc):
+    """VERDICT r1 #4: B = 16 at N = 256 within 2x one fit."""
+    import time
+    X_obs, Y, _, hyp = make_problem(None, orc, 6, 256, 64, B.hartmann6)
+    ctx.gp_set_data(X_obs, Y)
+    ls = np.tile(hyp["lenscale_sq"], (16, 1)) * np.linspace(0.8, 1.25, 16)[:, None]
+    args = (ls, hyp["amp"], hyp["noise"], hyp["mean"])
+    ctx.gp_nll_batch(*args)
+    ctx.gp_fit_hyp(ls[0], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+    ctx.sync()
+
+    def best_of(fn, reps=30):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    t1 = best_of(lambda: ctx.gp_fit_hyp(ls[0], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True))
+    t16 = best_of(lambda: ctx.gp_nll_batch(*args))
+    print("N = 256: one fit %.3f ms, 16 likelihoods in one batch %.3f ms" % (t1 * 1e3, t16 * 1e3))
+    assert t16 < 2.0 * t1
