@@ -74,7 +74,8 @@ struct b7_ctx {
   bool acc_valid = false;
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
-  int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain (B7_DIAG_VARIANT)
+  int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain with the DPP-fused
+                         // multiply-add, 2 = the same with mov_dpp + fma (the bit-for-bit reference of 1) (B7_DIAG_VARIANT)
   int inverse_inline = 1;  // build inv(L) inside the factorisation launches: 0 never (separate trtri passes), 1 for
                            // Npad <= 8192, 2 always (B7_INVERSE_INLINE)
   // 8 KiB of pinned, device-mapped host memory for the small blocks: [0, 2304) fit report, [2304, 2320) arg-max
@@ -86,8 +87,6 @@ struct b7_ctx {
   bool fmin_staged = false;  // the fmin staging slot of the pinned block holds a caller's values
   bool potrf_attrs_set = false;  // dynamic-LDS limits of the Cholesky kernels raised (once per context)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
-  bool diag_stamps = false, syrk_stamps = false;  // diagnostics: s_memtime phase stamps (B7_DIAG_STAMPS, B7_SYRK_STAMPS)
-  bool mlp_scalar = false;                       // force the scalar basis-network kernel (B7_MLP_SCALAR)
   int potrf_sched = 3;   // 1: one panel at a time (near update fused into the panel solve, far update riding on the
                          // next diagonal-block launch) for Npad <= 4096, 2: always; 0: panel groups with separate
                          // update launches; 3: ONE persistent launch for Npad <= 2048, else as 1 (B7_POTRF_SCHED)
@@ -95,9 +94,6 @@ struct b7_ctx {
   int potrf_defer = 1;   // far part of each trailing update rides on the next diagonal-block launch (B7_POTRF_DEFER)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
                          // N = 2048 (tools/potrf_ab.py): G = 1 1.068 ms, 2 1.067, 4 1.119, 8 1.274
-  int ksx_ablate = 0;    // diagnostic only (B7_KSX_ABLATE): drop stores / exp / MFMA from ksx_kernel to price them
-  int post_variant = 9;  // posterior.hip launch_post: 9 = 128x256 tile, 8 waves, odd LDS stride, zero-strip skip, static
-                         // priority raise for the younger half of the waves (B7_POST_VARIANT overrides)
   // ---- persistent Cholesky schedule (potrf_persist.hip)
   struct JobList { DevBuf buf; int n = 0; };
   std::map<int, JobList> pjobs_cache;  // job queues by (nb, mode)

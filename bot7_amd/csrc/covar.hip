@@ -114,10 +114,9 @@ __host__ __device__ constexpr int ksx_slab(int dpad) { return dpad >= 48 ? 32 : 
 
 // DPAD = padded input dimension, one of the classes {4, 8, 16, 32, 48, 64, 96} (b7_dpad_class): compile-time so that
 // the MFMA chain over DPAD/4 k-steps unrolls and the query fragments stay in registers for the whole block.
-// ABLATE (diagnostic, B7_KSX_ABLATE): 0 = product; 1 = no stores; 2 = no exp; 3 = no MFMA.
 // blockIdx.z = fit index of a batch over the same observations (b7_gp_nll_batch); all zero / null for a single fit
 using KBatch = KBatchDesc;
-template <int DPAD, int ABLATE>
+template <int DPAD>
 __global__ void __launch_bounds__(256)
     ksx_kernel(const double *__restrict__ xq, int64_t row0, int64_t Mtotal, int d, int dpad_rt, const double *w,
                const double *zsc, const double *zsh, const double *__restrict__ alpha, double amp, double meanc, int Npad,
@@ -221,14 +220,12 @@ __global__ void __launch_bounds__(256)
     for (int t = 0; t < KO / 16; ++t) {
       const double *ob = sob + (t * 16 + lr) * stride + lq;
       d4_t c = {0.0, 0.0, 0.0, 0.0};
-      if (ABLATE != 3) {
+      {
         double bf[KSTEPS];
 #pragma unroll
         for (int k4 = 0; k4 < KSTEPS; ++k4) bf[k4] = ob[4 * k4];
 #pragma unroll
         for (int k4 = 0; k4 < KSTEPS; ++k4) c = mfma_f64(qf[k4], bf[k4], c);
-      } else {
-        c[0] = c[1] = c[2] = c[3] = qf[0] * ob[0];
       }
       const double hk = sh[cur * KO + t * 16 + lr];
       const double al = sal[cur * KO + t * 16 + lr];
@@ -237,10 +234,10 @@ __global__ void __launch_bounds__(256)
       for (int r = 0; r < 4; ++r) {
         double arg = (c[r] - hq[r]) - hk;  // = -1/2 * (((-2 c) + xs) + zs), utils/math.lua:82
         arg = (arg > 0.0) ? 0.0 : arg;     // :106 clamp(0, huge) on the distance; NaN passes
-        kv[r] = (ABLATE == 2) ? amp * arg : amp * exp_nonpos(arg);
+        kv[r] = amp * exp_nonpos(arg);
         macc[r] = __builtin_fma(kv[r], al, macc[r]);
       }
-      if (ABLATE != 1) {
+      {
         // rows (lq, lq+4, lq+8, lq+12) x column lr  ->  16-byte stores of two adjacent columns
         const double s01 = pair_swap(odd ? kv[0] : kv[1]);
         const double s23 = pair_swap(odd ? kv[2] : kv[3]);
@@ -259,7 +256,7 @@ __global__ void __launch_bounds__(256)
     cur ^= 1;
   }
 
-  if (mu || ABLATE == 1) {
+  if (mu) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double v = macc[r];
@@ -268,8 +265,7 @@ __global__ void __launch_bounds__(256)
       v += __shfl_xor(v, 4);
       v += __shfl_xor(v, 8);
       const int64_t g = qbase + wave * 16 + lq + 4 * r;
-      if (lr == 0 && g < Mtotal && mu) mu[g] = meanc + v;
-      if (ABLATE == 1 && !mu && v == 1.2345e300) out[0] = v;  // keeps the arithmetic alive without stores
+      if (lr == 0 && g < Mtotal) mu[g] = meanc + v;
     }
   }
 }
@@ -299,10 +295,7 @@ template <int DPAD>
 int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mtotal, int d, const ObsSet &o,
                const double *alpha, double meanc, double *out, double *mu) {
   const size_t lds = ksx_lds_bytes(DPAD);
-  auto kern = ksx_kernel<DPAD, 0>;
-  if (c->ksx_ablate == 1) kern = ksx_kernel<DPAD, 1>;
-  if (c->ksx_ablate == 2) kern = ksx_kernel<DPAD, 2>;
-  if (c->ksx_ablate == 3) kern = ksx_kernel<DPAD, 3>;
+  auto kern = ksx_kernel<DPAD>;
   // dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup)
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));

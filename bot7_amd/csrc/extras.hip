@@ -335,7 +335,7 @@ int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const doubl
   if (M <= 0) return B7_OK;
   int maxw = 0;
   for (int i = 0; i <= n_layers; ++i) maxw = dd[i] > maxw ? dd[i] : maxw;
-  if (maxw <= 128 && !c->mlp_scalar) {  // MFMA path
+  if (maxw <= 128) {  // MFMA path
     const int stride = ((maxw + 15) & ~15) + 1;
     const int lds = (64 + 64) * stride * (int)sizeof(double);
     B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_mfma_kernel),

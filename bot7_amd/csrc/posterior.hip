@@ -11,10 +11,10 @@
 // The summation order is fixed (n-tiles ascending, then a fixed shuffle/LDS tree), so results are bitwise
 // reproducible run to run -- the arg-max downstream depends on that.
 //
-// Variants (A/B in one process on MI355X, N = 2048, 262144 candidates, tools/post_ab.py; all bitwise identical):
-//   0: 128x128 tile, 1 wave/SIMD 44.6 TF | 1: 2 blocks/CU 59.2 | 4: + odd LDS stride 59.7 | 5: + zero-strip skip
-//   61.3 | 6: both 61.6 | 7 (default): both on a 128(n) x 256(cand) tile, 8 waves 63.6 TF = 81 % of 78.6.
-// PMC on variant 1: MFMA pipe 87 % busy, effective clock 2.03 GHz (DVFS) -> 66.7 TF is the ceiling at that clock.
+// How the tile shape was chosen (A/B in one process on MI355X, N = 2048, 262144 candidates, round 1; all variants
+// bitwise identical): 128x128 tile, 1 wave/SIMD 44.6 TF | 2 blocks/CU 59.2 | + odd LDS stride 59.7 | + zero-strip skip
+// 61.3 | both 61.6 | both on a 128(n) x 256(cand) tile with 8 waves 63.6 | + static priority 64.7 TF = 82 % of 78.6.
+// PMC: MFMA pipe 84 % busy, effective clock 2.1 GHz (DVFS) -> 68 TF is the ceiling at that clock.
 //
 // Algorithmic work per launch: rows * Npad^2 flops (triangle exploited), bytes: the K* chunk is read
 // (t+1)/T-weighted ~ (T+1)/2 times from L2/MALL/HBM (T = Npad/128 n-tiles), Linv once per block from L2.
@@ -98,21 +98,10 @@ int launch_post_variant(b7_ctx *c, const double *ks, int64_t row0, int64_t rows,
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
   PhaseScope ps(c, "post");
   if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
-  int v = c->post_variant;
-  if ((v == 2 || v == 8) && (c->Npad % 256)) v = 9;
-  // fewer 256-candidate workgroups than CUs: the 128-wide tile fills the chip (N = 2048, M = 32768: 2.6 vs 4.2 ms;
-  // N = 256: 63 vs 83 us); a 64-wide one was slower again (4.1 ms)
-  if (v == 9 && rows / 256 < c->cus) v = 6;
-  switch (v) {
-    case 0: return launch_post_variant<128, 128, 2, 2, 1, 2, false>(c, ks, row0, rows, Mtotal, var);  // 1 wave/SIMD
-    case 2: return launch_post_variant<256, 128, 4, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, tall
-    case 3: return launch_post_variant<128, 256, 2, 4, 2, 2, false>(c, ks, row0, rows, Mtotal, var);  // 512 thr, wide
-    case 4: return launch_post_variant<128, 128, 2, 2, 2, 1, false>(c, ks, row0, rows, Mtotal, var);  // odd LDS stride
-    case 5: return launch_post_variant<128, 128, 2, 2, 2, 2, true>(c, ks, row0, rows, Mtotal, var);   // zero-strip skip
-    case 6: return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both
-    case 7: return launch_post_variant<128, 256, 2, 4, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, wide
-    case 8: return launch_post_variant<256, 128, 4, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);   // both, tall
-    case 9: return launch_post_variant<128, 256, 2, 4, 2, 1, true, true>(c, ks, row0, rows, Mtotal, var);  // 7 + priority
-    default: return launch_post_variant<128, 128, 2, 2, 2, 2, false>(c, ks, row0, rows, Mtotal, var); // 2 blocks/CU
-  }
+  // Two shapes, bitwise identical in output (the A/B ladder that led here is in DESIGN.md section 8): 128(n) x 256(cand)
+  // tile with 8 waves, odd LDS stride, zero-strip skip and a static priority raise for the younger half of the waves;
+  // with fewer 256-candidate workgroups than CUs the 128-wide tile fills the chip (N = 2048, M = 32768: 2.6 vs 4.2 ms;
+  // N = 256: 63 vs 83 us; a 64-wide one was slower again, 4.1 ms)
+  if (rows / 256 < c->cus) return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);
+  return launch_post_variant<128, 256, 2, 4, 2, 1, true, true>(c, ks, row0, rows, Mtotal, var);
 }

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256)
       // VAR 1: I_16 for the inversion recurrence lives in the block's unused upper-right 16x16 corner (rows 0..15,
       // columns 48..63: only blocks on or below the diagonal are ever touched); its neighbour (columns 32..47)
       // takes dummy stores
-      if (VAR == 1 && i < 16 && j2 >= 48) v[t] = make_double2(i == j2 - 48 ? 1.0 : 0.0, i == j2 - 47 ? 1.0 : 0.0);
+      if (VAR >= 1 && i < 16 && j2 >= 48) v[t] = make_double2(i == j2 - 48 ? 1.0 : 0.0, i == j2 - 47 ? 1.0 : 0.0);
       *reinterpret_cast<double2 *>(A + i * DLD + j2) = v[t];
       *reinterpret_cast<double2 *>(X + i * DLD + j2) = make_double2(0.0, 0.0);
     }
@@ -545,9 +545,7 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<0, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<1, true>),
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_syrk_small_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G64NT_K64::STAGE_DOUBLES * 8));
@@ -568,28 +566,14 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
     int nt = 0;
     if (with_inverse)
       for (int cc = 0; cc < (p + 1) / 2; ++cc) nt += (2 * cc + 2 < p) ? 2 * cc + 2 : p;
-    if (p == 0 && c->W.p && c->diag_stamps) {  // diagnostic: phase times inside the first diagonal block
-      unsigned long long *st = (unsigned long long *)c->W.p, h[20];
-      if (c->diag_variant == 0)
-        hipLaunchKernelGGL((potrf_diag_kernel<0, true>), dim3(nb > 1 ? 2 : 1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp, 0, 0, 0, 0, 0, nb);
-      else
-        hipLaunchKernelGGL((potrf_diag_kernel<1, true>), dim3(nb > 1 ? 2 : 1), dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
-                           (double *)c->dinv.p, (int *)c->info.p, st, Linv, Wp, 0, 0, 0, 0, 0, nb);
-      (void)hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream);
-      (void)hipStreamSynchronize(c->stream);
-      fprintf(stderr, "diag stamps (variant %d): load %llu |", c->diag_variant, h[1] - h[0]);
-      for (int kb = 0; kb < 4; ++kb)
-        fprintf(stderr, " kb%d: factor %llu sync %llu subpanel %llu update %llu |", kb,
-                h[2 + 4 * kb] - (kb ? h[1 + 4 * kb] : h[1]), h[3 + 4 * kb] - h[2 + 4 * kb],
-                h[4 + 4 * kb] - h[3 + 4 * kb], h[5 + 4 * kb] - h[4 + 4 * kb]);
-      fprintf(stderr, " doubling %llu store %llu total %llu\n", h[18] - h[17], h[19] - h[18], h[19] - h[0]);
-      return;
-    }
     const int ns = pend.tiles;
     const dim3 grid(1 + (p + 1 < nb ? 1 : 0) + nt + ns);  // factor, copier of the tile below, riders
     if (c->diag_variant == 0)
       hipLaunchKernelGGL(potrf_diag_kernel<0>, grid, dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
+                         (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp, nt,
+                         pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
+    else if (c->diag_variant == 2)
+      hipLaunchKernelGGL(potrf_diag_kernel<2>, grid, dim3(256), DIAG_LDS_BYTES, c->stream, L, n, p,
                          (double *)c->dinv.p, (int *)c->info.p, (unsigned long long *)nullptr, Linv, Wp, nt,
                          pend.kc0, pend.kb, pend.j0, pend.ncols, nb);
     else
@@ -612,28 +596,6 @@ int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
     int tiles = 0;
     for (int J = j0; J < j0 + ncols; ++J) tiles += nb - J;
     if (tiles <= 0) return;
-    if (c->syrk_stamps && kb == c->potrf_group && kc0 == 0) {  // diagnostic: per-block phase times of the first big update
-      unsigned long long *st = (unsigned long long *)c->W.p;  // W is allocated by gp_fit (not by b7_chol)
-      hipLaunchKernelGGL(potrf_syrk_kernel<true>, dim3(tiles), dim3(256), 0, c->stream, L, n, kc0, kb, j0, ncols, nb, st);
-      std::vector<unsigned long long> h((size_t)tiles * 4);
-      (void)hipMemcpyAsync(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
-      (void)hipStreamSynchronize(c->stream);
-      unsigned long long t0 = ~0ull, t1 = 0;
-      double s01 = 0, s12 = 0, s23 = 0;
-      for (int b = 0; b < tiles; ++b) {
-        t0 = h[b * 4] < t0 ? h[b * 4] : t0;
-        t1 = h[b * 4 + 3] > t1 ? h[b * 4 + 3] : t1;
-        s01 += h[b * 4 + 1] - h[b * 4];
-        s12 += h[b * 4 + 2] - h[b * 4 + 1];
-        s23 += h[b * 4 + 3] - h[b * 4 + 2];
-      }
-      unsigned long long lastStart = 0;
-      for (int b = 0; b < tiles; ++b) lastStart = h[b * 4] > lastStart ? h[b * 4] : lastStart;
-      fprintf(stderr, "syrk stamps: %d blocks; first start -> last end %llu cycles; last block started +%llu; mean per block: "
-                      "setup+C-prefetch-issue %.0f, gemm %.0f, epilogue %.0f\n",
-              tiles, t1 - t0, lastStart - t0, s01 / tiles, s12 / tiles, s23 / tiles);
-      return;
-    }
     if (tiles <= 256 && kb == 1 && c->syrk_small)
       hipLaunchKernelGGL(potrf_syrk_small_kernel<1>, dim3(tiles), dim3(256), G64NT_K64::STAGE_DOUBLES * 8, c->stream, L,
                          n, kc0, j0, ncols, nb);

@@ -48,6 +48,20 @@ __device__ __forceinline__ void fmac_share(double &acc, double src, double mul) 
                : "+v"(acc)
                : "v"(src), "v"(mul), "n"(J));
 }
+// The same broadcast multiply-add as two compiler-scheduled instructions (v_mov_b64_dpp + v_fma_f64): the reference form
+// of VAR 2, which tests/test_gpu_parity.py compares bit for bit with the asm form -- the hazard spacing around the
+// inline asm is hand-kept, and a compiler bump may reorder its neighbours.
+template <int J>
+__device__ __forceinline__ void fmac_share_ref(double &acc, double src, double mul) {
+  acc = __builtin_fma(row_share64<J>(src), mul, acc);
+}
+template <int VAR, int J>
+__device__ __forceinline__ void fmac_bcast(double &acc, double src, double mul) {
+  if constexpr (VAR == 2)
+    fmac_share_ref<J>(acc, src, mul);
+  else
+    fmac_share<J>(acc, src, mul);
+}
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -91,7 +105,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
   const int lr = lane & 15, lq = lane >> 4;
   for (int kb = 0; kb < 4; ++kb) {
     const int o = kb * 16;
-    if (VAR == 1 && wave == 0) {
+    if (VAR >= 1 && wave == 0) {
       // Square-root-free pivot chain, built for ISSUE cycles: one wave issues a VALU instruction every ~5 cycles
       // and this routine is bound by that, not by latency (tools/valu_probe.hip).  Lane lr keeps row lr of
       // C = L diag(sqrt(d)) (c_ij = l_ij sqrt(d_j), pivots d_j = c_jj).  Per column j: broadcast d_j, r_j = 1/d_j
@@ -128,13 +142,13 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
         const double nm = -(a[j] * r);  // -l~_ij of the LDL' form (rows i > j)
         static_for<16>([&](auto Kc) {
           constexpr int k = Kc;
-          if constexpr (k > j) fmac_share<k>(a[k], a[j], nm);  // c_ik -= l~_ij c_kj; a[j] was last written >= 2 asm ago
+          if constexpr (k > j) fmac_bcast<VAR, k>(a[k], a[j], nm);  // c_ik -= l~_ij c_kj; a[j] was last written >= 2 asm ago
         });
         // row j of the unit-lower inverse, lane lr holding column lr: x~_j = [j == lr] - sum_{k<j} c_jk (r_k x~_k)
         double sacc = 0.0;
         static_for<16>([&](auto Kc) {
           constexpr int k = Kc;
-          if constexpr (k < j) fmac_share<j>(sacc, a[k], xs[k]);
+          if constexpr (k < j) fmac_bcast<VAR, j>(sacc, a[k], xs[k]);
         });
         x[j] = rhs[j] - sacc;
         xs[j] = x[j] * r;
@@ -163,7 +177,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
         for (int k = 0; k < 16; ++k) A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
       }
     }
-    if (VAR == 1 && wave > 0 && kb > 0) {
+    if (VAR >= 1 && wave > 0 && kb > 0) {
       // while wave 0 factors: the previous step's update of the tiles right of block column kb, with the previous
       // step's panel (columns o - 16 ..).  kb = 1: (2,2) (3,2) (3,3); kb = 2: (3,3) again with panel 1; kb = 3: none.
       // Nothing wave 0 touches in this phase (tile (kb,kb), the rows (i,kb) below it, X) is read or written here.
@@ -267,7 +281,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
     // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4.  VAR 1 does only block column
     // kb + 1 here (all the next factor step reads); the tiles right of it were left to waves 1..3 of the NEXT
     // step's factor phase, where they idle anyway (see there).
-    if (VAR == 1) {
+    if (VAR >= 1) {
       const int i = kb + 1 + wave;
       if (i < 4) block16_update(A, i, kb + 1, o, lr, lq);
     } else {
@@ -284,8 +298,8 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
 
   // What is left of the inverse doubling (VAR 1 did the pair (0,1) and T = L[32:64,0:32] X[0:32,0:32] inside the
   // loop, on waves that were idle): the pair (2,3), then X[32:64, 0:32] = -X[32:64, 32:64] * T.
-  if (VAR == 1 ? wave == 0 : wave < 2) {
-    const int a0 = (VAR == 1 ? 1 : wave) * 32, c0 = a0 + 16;
+  if (VAR >= 1 ? wave == 0 : wave < 2) {
+    const int a0 = (VAR >= 1 ? 1 : wave) * 32, c0 = a0 + 16;
     d4_t t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)

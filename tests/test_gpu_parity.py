@@ -1373,3 +1373,33 @@ def test_nll_batch_sixteen_fits_cost_less_than_two(ctx, orc):
     t16 = best_of(lambda: ctx.gp_nll_batch(*args))
     print("N = 256: one fit %.3f ms, 16 likelihoods in one batch %.3f ms" % (t1 * 1e3, t16 * 1e3))
     assert t16 < 2.0 * t1
+
+
+@pytest.mark.parametrize("N", [64, 700, 2048])
+def test_dpp_fused_multiply_add_equals_its_two_instruction_form(orc, monkeypatch, N):
+    """potrf_diag.h's fmac_share is inline asm (v_fmac_f64_dpp row_newbcast) whose read-after-write spacing is kept by
+    hand; B7_DIAG_VARIANT=2 builds the same routine from v_mov_b64_dpp + v_fma_f64, which the compiler schedules and
+    pads itself.  Same arithmetic, so L, inv(L) and alpha must agree bit for bit (launch schedule on both sides: the
+    persistent one always uses the fused form)."""
+    import bot7_amd
+    ctxs = []
+    for var in ("1", "2"):
+        monkeypatch.setenv("B7_DIAG_VARIANT", var)
+        monkeypatch.setenv("B7_POTRF_SCHED", "1")
+        ctxs.append(bot7_amd.Context(0))
+    monkeypatch.delenv("B7_DIAG_VARIANT")
+    monkeypatch.delenv("B7_POTRF_SCHED")
+    try:
+        d = 6 if N < 2048 else 32
+        X_obs, Y, _, hyp = make_problem(None, orc, d, N, 64, B.hartmann6 if d == 6 else B.ackley)
+        out = []
+        for c in ctxs:
+            c.gp_fit(X_obs, Y, **hyp)
+            out.append(c.gp_download(N))
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+        f = orc.gp.fit(X_obs, Y, **hyp)
+        assert np.allclose(out[0][0], f.L, rtol=1e-9, atol=1e-12)
+    finally:
+        for c in ctxs:
+            c.close()

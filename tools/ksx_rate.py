@@ -1,4 +1,5 @@
-"""K(X*,X) assembly rate for several input dimensions (N = 2048, 262144 candidates per launch).  Diagnostic."""
+"""K(X*,X) assembly rate for several input dimensions (N = 2048, 262144 candidates per launch).  Diagnostic.
+usage: ksx_rate.py [d ...]"""
 import os
 import sys
 import numpy as np
@@ -6,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bot7_amd  # noqa: E402
 c = bot7_amd.Context(0)
 N, M = 2048, 262144
-for d in (2, 6, 16, 32, 39, 64):
+for d in ([int(a) for a in sys.argv[1:]] or (2, 6, 16, 32, 39, 64, 96)):
     X = c.grid_random(N, d, seed=3, row_offset=10 * M)
     Y = np.sin(X.sum(1, keepdims=True))
     c.grid_random(M, d, seed=3, download=False)
