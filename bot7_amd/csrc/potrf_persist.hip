@@ -42,7 +42,8 @@ namespace {
 
 using namespace b7diag;
 using GT = GemmF64<64, 64, 64, 2, 2, false>;  // NT, all of K = 64 in one LDS stage (row stride 66 = DLD)
-using GN = GemmF64<64, 64, 32, 2, 2, true>;   // NN, 32-deep stages: the inverse's partial products (as potrf.hip's G64NN)
+using GN = GemmF64<64, 64, 64, 2, 2, true>;   // NN: the inverse's partial products (potrf.hip's G64NN runs the same chain
+                                              // in 32-deep stages)
 static_assert(GT::STRIDE == DLD, "the trsm / look-ahead code reads GT's LDS image as [64][DLD]");
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
@@ -90,35 +91,14 @@ struct Flags {
   __device__ unsigned *pre_diag(int p) const { return base + FLAG_HDR + 2 * nb * nb + nb + p; }
 };
 
-// One lane polls ONE word, the workgroup learns the outcome through LDS.  false = abort (uniform): the caller returns.
-__device__ __forceinline__ bool wg_wait(unsigned *flag, const Flags &F, int *info, int *sh_ok, int code) {
-  if (threadIdx.x == 0) {
-    int ok = 1;
-    unsigned spins = 0;
-    while (ld_flag(flag) == 0u) {
-      __builtin_amdgcn_s_sleep(1);
-      ++spins;
-      if ((spins & 255u) == 0u && ld_flag(F.abort_word()) != 0u) {
-        ok = 0;
-        break;
-      }
-      if (spins > SPIN_LIMIT) {  // give up: everybody drains, the host falls back to the launch schedule
-        st_flag(F.abort_word(), (unsigned)code);
-        __hip_atomic_store(info + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    *sh_ok = ok;
-  }
-  __syncthreads();
-  const int ok = *sh_ok;
-  __syncthreads();  // sh_ok may be rewritten by the next wait
-  return ok != 0;
-}
-
-// Two words at once (lanes 0 and 1 poll one each): the critical workgroup's two hand-overs cost one round trip.
-__device__ __forceinline__ bool wg_wait2(unsigned *f0, unsigned *f1, const Flags &F, int *info, int *sh_ok, int code) {
+// Lanes 0 and 1 of wave 0 poll one word each (pass the same word twice to wait for one), the workgroup learns the
+// outcome through LDS.  false = abort (uniform): the caller returns.  ONE barrier per wait: the result goes to one of
+// two LDS slots used alternately (a slot is rewritten two waits later, and every thread has read it before it arrives
+// at the wait in between).  sh_ok: int[2]; `turn` is a per-thread counter that all threads advance together.
+__device__ __forceinline__ bool wg_wait2(unsigned *f0, unsigned *f1, const Flags &F, int *info, int *sh_ok, int &turn,
+                                         int code) {
+  const int slot = turn & 1;
+  turn += 1;
   if (threadIdx.x < 64) {
     unsigned *mine = (threadIdx.x & 1) ? f1 : f0;
     int ok = 1;
@@ -132,7 +112,7 @@ __device__ __forceinline__ bool wg_wait2(unsigned *f0, unsigned *f1, const Flags
         ok = 0;
         break;
       }
-      if (spins > SPIN_LIMIT) {
+      if (spins > SPIN_LIMIT) {  // give up: everybody drains, the host falls back to the launch schedule
         if (threadIdx.x == 0) {
           st_flag(F.abort_word(), (unsigned)code);
           __hip_atomic_store(info + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -141,12 +121,13 @@ __device__ __forceinline__ bool wg_wait2(unsigned *f0, unsigned *f1, const Flags
         break;
       }
     }
-    if (threadIdx.x == 0) *sh_ok = ok;
+    if (threadIdx.x == 0) sh_ok[slot] = ok;
   }
   __syncthreads();
-  const int ok = *sh_ok;
-  __syncthreads();
-  return ok != 0;
+  return sh_ok[slot] != 0;
+}
+__device__ __forceinline__ bool wg_wait(unsigned *flag, const Flags &F, int *info, int *sh_ok, int &turn, int code) {
+  return wg_wait2(flag, flag, F, info, sh_ok, turn, code);
 }
 
 // Every storing wave drains, the workgroup meets, ONE lane raises the flag (Guideline 16, R1).
@@ -304,6 +285,7 @@ __device__ constexpr int SUB_S[4][3] = {{0, 1, 2}, {3, 1, 2}, {3, 2, 0}, {3, 3, 
 __device__ constexpr int SUB_C[4][3] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 0}, {2, 3, 0}};
 
 __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *sh_ok, int *pf_done) {
+  int turn = 0;
   double *A = dsm, *X = dsm + NB * DLD, *T = X + NB * DLD, *S1 = T + 32 * TLD, *S2 = S1 + NB * DLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15,
             lq = lane >> 4;
@@ -339,7 +321,7 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       add_extra(d2, 1, a.nreal, a.extra);
     } else if (!last && (!have_d1 || !have_d2)) {
       unsigned *f1 = F.pre_sub(p + 1), *f2 = F.pre_diag(p + 1);
-      if (!wg_wait2(have_d1 ? f2 : f1, have_d2 ? f1 : f2, F, a.info, sh_ok, 100 + p)) return;
+      if (!wg_wait2(have_d1 ? f2 : f1, have_d2 ? f1 : f2, F, a.info, sh_ok, turn, 100 + p)) return;
       if (!have_d1) tile_load_sc1(d1, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
       if (!have_d2) tile_load_sc1(d2, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB, n);
     }
@@ -472,7 +454,7 @@ __device__ __forceinline__ void acc_to_lds(const d4_t (&C)[2][2], double *img, i
 }
 
 // tile (I, J) of the lower triangle, I > J (type JOB_TILE / JOB_PRE_SUB) or I == J (JOB_PRE_DIAG)
-__device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J, double *sm, int *sh_ok) {
+__device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J, double *sm, int *sh_ok, int &turn) {
   const int n = a.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   d4_t C[2][2];
@@ -492,15 +474,14 @@ __device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J,
   }
   const int nupd = (type == JOB_PRE_DIAG) ? J - 1 : J;  // the critical workgroup applies panel J-1 to its own diagonal tile
   for (int q = 0; q < nupd; ++q) {
-    if (I != J && !wg_wait(F.ready(J, q), F, a.info, sh_ok, 1000 + J * 64 + q)) return false;
-    if (!wg_wait(F.ready(I, q), F, a.info, sh_ok, 1000 + I * 64 + q)) return false;
+    if (!wg_wait2(F.ready(I, q), F.ready(J, q), F, a.info, sh_ok, turn, 1000 + I * 64 + q)) return false;
     apply_update(C, a.L + ((int64_t)I * NB) * n + (int64_t)q * NB, a.L + ((int64_t)J * NB) * n + (int64_t)q * NB, n, sm);
   }
   double *Ai = sm, *Xp = sm + NB * DLD;
   double *dst = a.L + ((int64_t)I * NB) * n + (int64_t)J * NB;
   acc_to_lds(C, Ai, DLD);
   if (type == JOB_TILE) {
-    if (!wg_wait(F.ready(J, J), F, a.info, sh_ok, 5000 + J)) return false;
+    if (!wg_wait(F.ready(J, J), F, a.info, sh_ok, turn, 5000 + J)) return false;
     d2_t vx[8];
     tile_load_sc1(vx, a.dinv + (int64_t)J * NB * NB, NB);
     tile_to_lds(vx, Xp);
@@ -534,34 +515,32 @@ __device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J,
 }
 
 // tile (p, j), j < p, of inv(L)
-__device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm, int *sh_ok) {
+__device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm, int *sh_ok, int &turn) {
   const int n = a.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   d4_t tot[2][2] = {}, cur[2][2] = {};
   for (int t = j; t < p; ++t) {
-    if (!wg_wait(F.ready(p, t), F, a.info, sh_ok, 10000 + p * 64 + t)) return false;
-    if (!wg_wait(t == j ? F.ready(j, j) : F.iready(t, j), F, a.info, sh_ok, 20000 + t * 64 + j)) return false;
+    if (!wg_wait2(F.ready(p, t), t == j ? F.ready(j, j) : F.iready(t, j), F, a.info, sh_ok, turn, 10000 + p * 64 + t)) return false;
     const double *Lpt = a.L + ((int64_t)p * NB) * n + (int64_t)t * NB;
     // rows [64 t, 64 t + 64) x columns [64 j, ..) of inv(L); the diagonal tile is inv(L_jj) itself
     const double *Btile = (t == j) ? a.dinv + (int64_t)j * NB * NB : a.Linv + ((int64_t)t * NB) * n + (int64_t)j * NB;
     const int ldb = (t == j) ? NB : n;
     const __amdgpu_buffer_rsrc_t ra = tile_rsrc(Lpt), rb = tile_rsrc(Btile);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {  // two 32-deep stages, the chain runs on through both (and through a chunk's 2nd tile)
+    {  // the whole 64-deep tile pair in one LDS stage: the same k-ascending chain as two 32-deep stages, one round trip
       GN::Regs r;
 #pragma unroll
       for (int i = 0; i < GN::A_PER_T; ++i) {
-        const int c = tid + i * 256, row = c / 16, kc = c % 16;
-        r.a[i] = ld16_sc1(ra, (row * n + 32 * h + 2 * kc) * 8);
+        const int c = tid + i * 256, row = c / 32, kc = c % 32;
+        r.a[i] = ld16_sc1(ra, (row * n + 2 * kc) * 8);
       }
 #pragma unroll
       for (int i = 0; i < GN::B_PER_T; ++i) {
         const int c = tid + i * 256, kr = c / 32, nc = c % 32;
-        r.b[i] = ld16_sc1(rb, ((32 * h + kr) * ldb + 2 * nc) * 8);
+        r.b[i] = ld16_sc1(rb, (kr * ldb + 2 * nc) * 8);
       }
       GN::store_lds(r, sm);
       __syncthreads();
-      GN::compute_stage(sm, cur);
+      GN::compute_stage(sm, cur);  // the chain runs on through a chunk's second tile
       __syncthreads();
     }
     if ((t & 1) == 1 || t == p - 1) {  // end of the 128-deep chunk t / 2: partials are summed in ascending chunk order
@@ -574,7 +553,7 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
         }
     }
   }
-  if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, 30000 + p)) return false;
+  if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, turn, 30000 + p)) return false;
   constexpr int SLD = 65;  // odd stride: the B-operand reads (k = lane >> 4, n = lane & 15) stay conflict-free
   double *Dn = sm, *Ts = sm + NB * DLD;
   {
@@ -617,14 +596,14 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
 
 // L z = r by forward substitution, block row by block row as the tiles of L are published; |z|^2 and sum log L_ii are
 // all the likelihood needs (no inverse, no alpha).  One workgroup per fit; thread t: row t >> 2, a quarter of the columns.
-__device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok) {
+__device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok, int &turn) {
   const int n = a.n, nb = a.nb, tid = threadIdx.x, row = tid >> 2, part = tid & 3;
   double *z = sm, *accs = sm + 64 * 64, *red = accs + 64;
   double ssq = 0.0, logdet = 0.0;
   for (int p = 0; p < nb; ++p) {
     double acc = 0.0;
     for (int q = 0; q < p; ++q) {
-      if (!wg_wait(F.ready(p, q), F, a.info, sh_ok, 50000 + p * 64 + q)) return false;
+      if (!wg_wait(F.ready(p, q), F, a.info, sh_ok, turn, 50000 + p * 64 + q)) return false;
       const __amdgpu_buffer_rsrc_t rs = tile_rsrc(a.L + ((int64_t)p * NB) * n + (int64_t)q * NB);
       d2_t v[8];
 #pragma unroll
@@ -638,7 +617,7 @@ __device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok) 
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (part == 0) accs[row] = a.resid[p * 64 + row] - acc;
-    if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, 60000 + p)) return false;  // its barrier publishes accs
+    if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, turn, 60000 + p)) return false;  // its barrier publishes accs
     const __amdgpu_buffer_rsrc_t rd = tile_rsrc(a.dinv + (int64_t)p * NB * NB);
     double sz = 0.0;
     {
@@ -682,7 +661,7 @@ __device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok) 
 
 __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
   extern __shared__ __align__(16) double dsm[];
-  __shared__ int sh_ok, sh_job, pf_done[4];
+  __shared__ int sh_ok[2], sh_job, pf_done[4];
   {
     const int64_t b = blockIdx.y;  // one factorisation per grid row
     a.K += b * a.sK;
@@ -697,10 +676,11 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
   }
   const Flags F{a.flags, a.nb};
   if (blockIdx.x == 0) {
-    critical_path(a, F, dsm, &sh_ok, pf_done);
+    critical_path(a, F, dsm, sh_ok, pf_done);
     return;
   }
   const int n = a.n;
+  int turn = 0;
   for (;;) {
     if (threadIdx.x == 0)
       sh_job = (int)__hip_atomic_fetch_add(F.head(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -715,13 +695,13 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
     if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 2] = __builtin_amdgcn_s_memtime();
     bool ok = true;
     if (type == JOB_TILE || type == JOB_PRE_SUB || type == JOB_PRE_DIAG) {
-      ok = tile_job(a, F, type, I, J, dsm, &sh_ok);
+      ok = tile_job(a, F, type, I, J, dsm, sh_ok, turn);
     } else if (type == JOB_INV) {
-      ok = inv_job(a, F, I, J, dsm, &sh_ok);
+      ok = inv_job(a, F, I, J, dsm, sh_ok, turn);
     } else if (type == JOB_VEC) {
-      ok = vec_job(a, F, dsm, &sh_ok);
+      ok = vec_job(a, F, dsm, sh_ok, turn);
     } else if (type == JOB_INV_DIAG) {  // inv(L)[p][p] = inv(L_pp): nobody inside the launch reads it
-      ok = wg_wait(F.ready(I, I), F, a.info, &sh_ok, 40000 + I);
+      ok = wg_wait(F.ready(I, I), F, a.info, sh_ok, turn, 40000 + I);
       if (ok) {
         d2_t v[8];
         tile_load_sc1(v, a.dinv + (int64_t)I * NB * NB, NB);
