@@ -1,7 +1,7 @@
 """Per-launch PMC summary of the two dominant kernels from separate rocprofv3 --pmc passes of bench.py.
-usage: pmc_summary.py <dir-of-pass-dirs> <out.json>
+usage: pmc_summary.py <dir-of-pass-dirs> <out.json> [note]
 Each pass:  rocprofv3 --kernel-trace --pmc <COUNTERS> -d <dir>/<pass> --output-format csv --
-            python3 bench.py --steps 1 --warmup 1 --candidates 262144 --no-cpu-baseline
+            python3 bench.py --steps 1 --warmup 1 --candidates 262144 --no-cpu-baseline --no-extras
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half the bytes of wide
 coalesced reads), WRITE_SIZE is taken as is.  GRBM_GUI_ACTIVE / 8 XCDs / kernel time = effective clock."""
 import csv
@@ -56,5 +56,10 @@ for k in ("post_kernel", "ksx_kernel"):
         # summed over the 8 XCDs)
         e["mfma_busy_frac_of_simd_cycles"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] / 8 * 1024)
     res["kernels"][k] = e
+res.update({"rows_per_launch": 262144, "n_obs": 2048, "d": 32,
+            "note": (sys.argv[3] if len(sys.argv) > 3 else "") + " FETCH_SIZE/WRITE_SIZE are in KiB and count the L2's fabric-side "
+                    "requests (Infinity-Cache hits included: profiles/r02_workspace_experiment.json); FETCH_SIZE doubled per "
+                    "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE taken as is; made by "
+                    "tools/pmc_summary.py"})
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
