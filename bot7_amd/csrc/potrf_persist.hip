@@ -60,7 +60,8 @@ struct PArgs {
   double *L, *Linv, *dinv;
   unsigned *flags;
   int *info;
-  unsigned long long *stamps;  // nullable: [nb][8] critical-path stamps, then [njobs][2] job start / end
+  unsigned long long *stamps;  // nullable: [nb][8] critical-path stamps, then [njobs][4]: job start, end, cycles spent in
+                               // trailing-update products (load + stage + MFMA + subtract), number of such products
   const int4 *jobs;
   int njobs, n, nb, nreal, with_inverse;
   double extra;
@@ -454,7 +455,7 @@ __device__ __forceinline__ void acc_to_lds(const d4_t (&C)[2][2], double *img, i
 }
 
 // tile (I, J) of the lower triangle, I > J (type JOB_TILE / JOB_PRE_SUB) or I == J (JOB_PRE_DIAG)
-__device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J, double *sm, int *sh_ok, int &turn) {
+__device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J, double *sm, int *sh_ok, int &turn, int jid) {
   const int n = a.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   d4_t C[2][2];
@@ -473,9 +474,16 @@ __device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J,
         }
   }
   const int nupd = (type == JOB_PRE_DIAG) ? J - 1 : J;  // the critical workgroup applies panel J-1 to its own diagonal tile
+  unsigned long long busy = 0;
   for (int q = 0; q < nupd; ++q) {
     if (!wg_wait2(F.ready(I, q), F.ready(J, q), F, a.info, sh_ok, turn, 1000 + I * 64 + q)) return false;
+    const unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     apply_update(C, a.L + ((int64_t)I * NB) * n + (int64_t)q * NB, a.L + ((int64_t)J * NB) * n + (int64_t)q * NB, n, sm);
+    if (a.stamps) busy += __builtin_amdgcn_s_memtime() - t0;
+  }
+  if (a.stamps && tid == 0) {
+    a.stamps[a.nb * 8 + jid * 4 + 2] = busy;
+    a.stamps[a.nb * 8 + jid * 4 + 3] = (unsigned long long)nupd;
   }
   double *Ai = sm, *Xp = sm + NB * DLD;
   double *dst = a.L + ((int64_t)I * NB) * n + (int64_t)J * NB;
@@ -692,10 +700,10 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
     const int4 job = a.jobs[jid];
     const int type = __builtin_amdgcn_readfirstlane(job.x), I = __builtin_amdgcn_readfirstlane(job.y),
               J = __builtin_amdgcn_readfirstlane(job.z);
-    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 2] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 4] = __builtin_amdgcn_s_memtime();
     bool ok = true;
     if (type == JOB_TILE || type == JOB_PRE_SUB || type == JOB_PRE_DIAG) {
-      ok = tile_job(a, F, type, I, J, dsm, sh_ok, turn);
+      ok = tile_job(a, F, type, I, J, dsm, sh_ok, turn, jid);
     } else if (type == JOB_INV) {
       ok = inv_job(a, F, I, J, dsm, sh_ok, turn);
     } else if (type == JOB_VEC) {
@@ -714,7 +722,7 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
       tile_store_plain(z, a.L + ((int64_t)I * NB) * n + (int64_t)J * NB, n);
       if (a.with_inverse) tile_store_plain(z, a.Linv + ((int64_t)I * NB) * n + (int64_t)J * NB, n);
     }
-    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 2 + 1] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 4 + 1] = __builtin_amdgcn_s_memtime();
     if (!ok) return;
   }
 }
@@ -805,7 +813,7 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
   c->pjobs_nb = nb;
   c->pjobs_n = njobs;
   if (c->persist_stamps) {
-    const size_t words = (size_t)nb * 8 + (size_t)njobs * 2;
+    const size_t words = (size_t)nb * 8 + (size_t)njobs * 4;
     B7_TRY(b7_ensure(c, c->pstamps, sizeof(unsigned long long) * words));
     B7_HIP(c, hipMemsetAsync(c->pstamps.p, 0, sizeof(unsigned long long) * words, c->stream));
     a.stamps = (unsigned long long *)c->pstamps.p;
@@ -881,10 +889,10 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
 
 size_t persist_flag_words_host(int nb) { return persist_flag_words(nb); }
 
-// diagnostics (tools/persist_stamps.py): the stamps of the last persistent launch, [nb][8] then [njobs][2]
+// diagnostics (tools/persist_stamps.py): the stamps of the last persistent launch, [nb][8] then [njobs][4]
 extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_words, int *nb_out, int *njobs_out) {
   if (!c->pstamps.p) return B7_ERR_STATE;
-  const int words = c->pjobs_nb * 8 + c->pjobs_n * 2;
+  const int words = c->pjobs_nb * 8 + c->pjobs_n * 4;
   if (nb_out) *nb_out = c->pjobs_nb;
   if (njobs_out) *njobs_out = c->pjobs_n;
   B7_HIP(c, hipStreamSynchronize(c->stream));

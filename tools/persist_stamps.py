@@ -29,7 +29,7 @@ rc = L.b7dbg_persist_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size, C.by
 assert rc == 0, rc
 nb, nj = nb.value, nj.value
 crit = buf[:nb * 8].reshape(nb, 8).astype(np.int64)
-jobs = buf[nb * 8:nb * 8 + nj * 2].reshape(nj, 2).astype(np.int64)
+jobs = buf[nb * 8:nb * 8 + nj * 4].reshape(nj, 4).astype(np.int64)
 t0 = crit[0, 0]
 GHZ = 2.4
 names = ["factor", "wait+issue D1", "stores+D1->LDS", "trsm", "wait+load D2", "update", "publish"]
@@ -46,6 +46,13 @@ print("mean   %8s  " % "" + "  ".join("%-14.2f" % v for v in tot / (nb - 1)))
 print("critical path total %.1f us (first factor start -> last factor end)" % ((crit[nb - 1, 1] - t0) / GHZ / 1e3))
 print("workgroup 0: entry -> first factor %.1f us; last factor end -> exit %.1f us; entry -> exit %.1f us" % (
     (t0 - crit[nb - 1, 6]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 1]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 6]) / GHZ / 1e3))
-started = jobs[:, 0] > 0
-print("jobs: %d of %d stamped; last job end %.1f us after start; median job duration %.1f us" % (
-    started.sum(), nj, (jobs[started, 1].max() - t0) / GHZ / 1e3, float(np.median((jobs[started, 1] - jobs[started, 0]))) / GHZ / 1e3))
+upd = jobs[jobs[:, 3] > 0]
+flop = float(upd[:, 3].sum()) * 2 * 64 ** 3
+secs = float(upd[:, 2].sum()) / (GHZ * 1e9)
+cu_peak = 78.6e12 / 256
+print("trailing updates in helper jobs: %d products of 64x64x64 in %d jobs, %.2f us each (wait for the two tiles excluded: sc1 "
+      "loads, LDS stage, 64-deep MFMA chains, subtraction) = %.3f TFLOP/s per CU = %.1f %% of one CU's fp64-MFMA peak (%.3f)"
+      % (upd[:, 3].sum(), len(upd), secs / upd[:, 3].sum() * 1e6, flop / secs / 1e12, 100 * flop / secs / cu_peak, cu_peak / 1e12))
+print("whole launch: N^3/3 = %.2f GFLOP of trailing updates over %.1f us of critical path = %.1f %% of the chip's fp64-MFMA peak "
+      "(the schedule is bound by the one-CU factorisation chain, not by the updates)"
+      % (N ** 3 / 3 / 1e9, (crit[nb - 1, 1] - t0) / GHZ / 1e3, 100 * (N ** 3 / 3) / ((crit[nb - 1, 1] - t0) / GHZ / 1e9) / 78.6e12))
