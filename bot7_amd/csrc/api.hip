@@ -135,6 +135,7 @@ int b7_create(b7_ctx **out, int device_id) {
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
   c->persist_stamps = getenv("B7_PERSIST_STAMPS") != nullptr;
   if (const char *pv = getenv("B7_PERSIST_HELPERS")) c->persist_helpers = atoi(pv);
+  if (const char *pv = getenv("B7_PERSIST_FAULT")) c->persist_fault = atoi(pv);
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {

@@ -105,6 +105,7 @@ struct b7_ctx {
   bool persist_attr_set = false, persist_stamps = false;
   int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
+  int persist_fault = -1;    // tests only (B7_PERSIST_FAULT): panel whose flag workgroup 0 withholds, to exercise the time-out
   int potrf_sched_saved = 0; // the schedule to return to after such a redo
   DevBuf part;   // argmax partials (value, index)
   DevBuf scratch; // misc (fmin upload, results)

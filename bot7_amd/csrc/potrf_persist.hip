@@ -72,6 +72,7 @@ struct PArgs {
   // terms[0] = |z|^2, terms[1] = sum log L_ii
   const double *resid;
   double *terms;
+  int fault_panel;  // tests only (B7_PERSIST_FAULT=p): workgroup 0 never raises ready(p, p); -1 = off
 };
 
 // ---- flags ---------------------------------------------------------------------------------------------------------
@@ -384,7 +385,7 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     __syncthreads();
     PST(p, 4);
     // L_pp and inv(L_pp) were issued a triangular solve ago: the drain inside the publish is (nearly) free by now
-    wg_publish(F.ready(p, p));
+    if (p != a.fault_panel) wg_publish(F.ready(p, p));
     {
       d2_t vl[8];
       tile_from_lds(vl, S1);
@@ -797,6 +798,7 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
   c->linv_done = false;
   B7_TRY(b7_ensure(c, c->pflags, sizeof(unsigned) * persist_flag_words(nb)));
   PArgs a = {};
+  a.fault_panel = c->persist_fault;
   a.K = (const double *)c->K.p;
   a.L = (double *)c->L.p;
   a.Linv = with_inverse ? (double *)c->Linv.p : nullptr;
@@ -844,6 +846,7 @@ int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv,
   for (int b0 = 0; b0 < B; b0 += per_launch) {
     const int nb_here = B - b0 < per_launch ? B - b0 : per_launch;
     PArgs a = {};
+    a.fault_panel = -1;
     a.K = K + b0 * nn;
     a.L = L + b0 * nn;
     a.dinv = dinv + (int64_t)b0 * n * NB;
@@ -873,6 +876,7 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
   int njobs = 0;
   B7_TRY(persist_jobs(c, nb, 2, &jobs, &njobs));
   PArgs a = {};
+  a.fault_panel = -1;
   a.K = K;
   a.L = L;
   a.dinv = dinv;

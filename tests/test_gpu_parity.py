@@ -1403,3 +1403,67 @@ def test_dpp_fused_multiply_add_equals_its_two_instruction_form(orc, monkeypatch
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("helpers", [1, 3, 17])
+def test_persistent_cholesky_cannot_deadlock_with_few_helpers(orc, monkeypatch, helpers):
+    """The job queue is a topological order of the tile dependencies, so any number of helper workgroups >= 1 must get
+    through it (only slower): one, three and seventeen helpers reproduce the launch schedule's bits without a time-out."""
+    import bot7_amd
+    monkeypatch.setenv("B7_PERSIST_HELPERS", str(helpers))
+    launch, persist = _two_schedules(monkeypatch)
+    monkeypatch.delenv("B7_PERSIST_HELPERS")
+    try:
+        for N, d, obj in ((300, 6, B.hartmann6), (1100, 6, B.hartmann6)):
+            X_obs, Y, _, hyp = make_problem(None, orc, d, N, 64, obj)
+            out = []
+            for c in (launch, persist):
+                r = c.gp_fit(X_obs, Y, want_nll=True, **hyp)
+                out.append(c.gp_download(N) + (r["nll"],))
+            for a, b in zip(*out):
+                assert np.array_equal(a, b)
+        assert _aborts(persist) == 0
+    finally:
+        launch.close()
+        persist.close()
+
+
+def test_persistent_cholesky_times_out_into_the_launch_schedule(orc, monkeypatch):
+    """Fault injection: workgroup 0 withholds one hand-off flag (B7_PERSIST_FAULT).  Its consumers must run into their
+    bounded spin, raise the abort word, every workgroup must drain (the launch ends, no hang), and the host must redo
+    the factorisation with the launch schedule -- same bits, one abort counted, and the context keeps working."""
+    import bot7_amd
+    monkeypatch.setenv("B7_PERSIST_FAULT", "2")
+    launch, persist = _two_schedules(monkeypatch)
+    monkeypatch.delenv("B7_PERSIST_FAULT")
+    try:
+        X_obs, Y, X_hid, hyp = make_problem(None, orc, 6, 500, 700, B.hartmann6)
+        out = []
+        for c in (launch, persist):
+            r = c.gp_fit(X_obs, Y, want_nll=True, **hyp)
+            out.append(c.gp_download(500) + (r["nll"],))
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+        assert _aborts(persist) == 1
+        persist.grid_upload(X_hid)
+        mu, var = persist.gp_predict()
+        mu_o, var_o = orc.gp.predict(orc.gp.fit(X_obs, Y, **hyp), X_hid)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+        # a matrix with fewer panels than the faulty one is unaffected
+        r = persist.gp_fit(X_obs[:100], Y[:100], want_nll=True, **hyp)
+        assert _aborts(persist) == 1 and np.isfinite(r["nll"]).all()
+    finally:
+        launch.close()
+        persist.close()
+
+
+def test_nll_batch_more_fits_than_fit_on_the_chip(ctx, orc):
+    X_obs, Y, _, hyp = make_problem(None, orc, 6, 200, 64, B.hartmann6)
+    ctx.gp_set_data(X_obs, Y)
+    Bn = 70                                           # 28 fits per launch at Npad = 256: three launches
+    scale = np.linspace(0.6, 1.6, Bn)
+    nll = ctx.gp_nll_batch(hyp["lenscale_sq"][None, :] * scale[:, None], hyp["amp"], hyp["noise"], hyp["mean"])
+    for b in (0, 27, 28, 55, 56, 69):
+        f = orc.gp.fit(X_obs, Y, hyp["lenscale_sq"] * scale[b], hyp["amp"], hyp["noise"], hyp["mean"])
+        assert nll[b] == pytest.approx(float(f.nll[0]), rel=1e-9, abs=1e-7)
+    assert np.all(np.diff(nll) != 0)
