@@ -95,6 +95,25 @@ end
 
 function model:nll(X_obs, Y_obs, hyp) return self:fit(X_obs, Y_obs, hyp or self.hyp, true) end
 
+-- B likelihoods at once (thetas: B x (d+3) rows in the hyper-vector layout above): one persistent launch for all of them,
+-- the current fit stays as it is.  For multi-chain samplers and speculative step-out probes.
+function model:nll_batch(X_obs, Y_obs, thetas)
+  local X = hip.pin(X_obs)
+  local Y = hip.pin(Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs)
+  if not (same_data(self, X, Y) and X_obs:isContiguous() and Y_obs:isContiguous()) then
+    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))
+    self._data = {xp = torch.data(X), yp = torch.data(Y), n = X:size(1), d = X:size(2), c = Y:size(2),
+                  xs = X:sum(), ys = Y:sum()}
+  end
+  local B, d = thetas:size(1), thetas:size(2) - 3
+  local ls   = thetas:narrow(2, 1, d):contiguous()
+  local amp, noise, mean = thetas:select(2, d + 1):contiguous(), thetas:select(2, d + 2):contiguous(), thetas:select(2, d + 3):contiguous()
+  local out  = torch.DoubleTensor(B)
+  hip.check(hip.C.b7_gp_nll_batch(hip.ctx, B, torch.data(ls), torch.data(amp), torch.data(noise), torch.data(mean),
+                                  torch.data(out), nil, nil))
+  return out
+end
+
 -- -NLL on the device + flat prior inside the bounds (-inf outside): the density bot7.samplers.slice evaluates
 function model:log_posterior(theta, X_obs, Y_obs)
   local theta = theta:view(-1)
