@@ -168,7 +168,7 @@ void b7_destroy(b7_ctx *c) {
   (void)b7_comm_destroy(c);
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
-                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pflags, &c->pstamps,
+                   &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pstamps,
                    &c->bhyp, &c->bw, &c->bzsc, &c->bzss, &c->bK, &c->bL, &c->bdinv, &c->bflags, &c->binfo, &c->bresid, &c->bterms};
   for (auto &kv : c->pjobs_cache) b7_release(kv.second.buf);
   for (DevBuf *b : all) b7_release(*b);
@@ -364,8 +364,6 @@ static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse);
 void persist_gave_up(b7_ctx *c);
 static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse);
 static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse);
-// device result block of a fit: int info[4] | double nll_terms[1 + 256]
-static constexpr size_t B7_INFO_BYTES = 16 + sizeof(double) * 257;
 
 // Y - mean on the device (padding rows zero): the sampler changes only the hypers, the data stay where they are
 __global__ void __launch_bounds__(256) resid_kernel(const double *__restrict__ y, double *__restrict__ r, int64_t nreal,

@@ -20,6 +20,12 @@ static inline int b7_dpad_class(int d) {
   return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : 96;
 }
 
+// Device result block of a fit: int info[4] | double nll_terms[1 + 256] | the persistent schedule's hand-off flags (up to
+// nb = 32 panels), so that ONE memset ahead of a persistent launch zeroes info and flags together.
+constexpr size_t B7_INFO_HEAD_BYTES = 16 + sizeof(double) * 257 + 8;                       // 2080: a multiple of 16
+constexpr size_t B7_PERSIST_FLAG_WORDS_MAX = 16 + 2 * 32 * 32 + 2 * 32;                    // FLAG_HDR + 2 nb^2 + 2 nb
+constexpr size_t B7_INFO_BYTES = B7_INFO_HEAD_BYTES + 4 * B7_PERSIST_FLAG_WORDS_MAX;
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -97,7 +103,6 @@ struct b7_ctx {
   // ---- persistent Cholesky schedule (potrf_persist.hip)
   struct JobList { DevBuf buf; int n = 0; };
   std::map<int, JobList> pjobs_cache;  // job queues by (nb, mode)
-  DevBuf pflags;   // hand-off flags, zeroed ahead of every launch
   DevBuf pstamps;  // diagnostics (B7_PERSIST_STAMPS)
   int pjobs_nb = 0, pjobs_n = 0;   // shape of the last single persistent launch (for the stamp reader)
   // b7_gp_nll_batch: B fits of the resident data in likelihood mode

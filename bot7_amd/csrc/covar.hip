@@ -50,12 +50,14 @@ __global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__
   int nrows = N - row0;
   nrows = nrows < 0 ? 0 : (nrows > 64 ? 64 : nrows);
   const double *src = xobs + (int64_t)row0 * d;
-  for (int e = lane; e < nrows * d; e += 64) {
+#pragma unroll 8
+  for (int e = lane; e < nrows * d; e += 64) {  // unrolled: eight loads in flight (a load -> wait -> LDS store loop was 21 us)
     const int r = e / d, k = e - r * d;
     tile[r * tld + k] = src[e];
   }
   __syncthreads();
   double s = 0.0;
+#pragma unroll 8
   for (int k = 0; k < dpad; ++k) {
     const double z = (lane < nrows && k < d) ? tile[lane * tld + k] : 0.0;
     const double wk = wl[k];
@@ -65,6 +67,7 @@ __global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__
   if (row0 + lane < Npad) zsh[row0 + lane] = (lane < nrows) ? 0.5 * s : __builtin_inf();
   __syncthreads();
   double *dst = zsc + (int64_t)row0 * dpad;
+#pragma unroll 8
   for (int e = lane; e < 64 * dpad; e += 64) {
     const int r = e / dpad, k = e - r * dpad;
     if (row0 + r < Npad) dst[e] = tile[r * tld + k];

@@ -452,7 +452,19 @@ __global__ void __launch_bounds__(256)
   if (row >= n) return;
   for (int cidx = 0; cidx < ycols; ++cidx) {
     double s = 0.0;
-    for (int k = lane; k <= row; k += 64) s += Linv[(int64_t)row * n + k] * r[(int64_t)k * ycols + cidx];
+    // eight loads of each operand in flight per lane; the sum runs in the same order as the plain loop (same bits)
+    for (int k0 = lane; k0 <= row; k0 += 64 * 8) {
+      double av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 64 * u;
+        av[u] = k <= row ? Linv[(int64_t)row * n + k] : 0.0;
+        bv[u] = k <= row ? r[(int64_t)k * ycols + cidx] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + 64 * u <= row) s += av[u] * bv[u];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) t[(int64_t)row * ycols + cidx] = s;
   }
@@ -484,8 +496,18 @@ __global__ void __launch_bounds__(256)
   const int r0 = blockIdx.y * TSL + wave * 64;
   for (int cidx = 0; cidx < ycols; ++cidx) {
     double s = 0.0;
-    if (r0 < n && r0 + 63 >= blockIdx.x * 64)  // Linv[i][col] = 0 for i < col: slices above the diagonal are zero
-      for (int i = r0; i < r0 + 64; ++i) s += Linv[(int64_t)i * n + col] * t[(int64_t)i * ycols + cidx];
+    if (r0 < n && r0 + 63 >= blockIdx.x * 64) {  // Linv[i][col] = 0 for i < col: slices above the diagonal are zero
+      for (int i0 = r0; i0 < r0 + 64; i0 += 16) {  // sixteen rows in flight; summed in row order (same bits as a plain loop)
+        double av[16], tv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          av[u] = Linv[(int64_t)(i0 + u) * n + col];
+          tv[u] = t[(int64_t)(i0 + u) * ycols + cidx];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += av[u] * tv[u];
+      }
+    }
     red[wave][threadIdx.x & 63] = s;
     __syncthreads();
     if (wave == 0)

@@ -93,8 +93,11 @@ struct NoHook {
   __device__ __forceinline__ void operator()(int, int) const {}
 };
 // hook(kb, wave) runs on waves 1..3 (VAR 1) at the end of their share of step kb's factor phase, i.e. in time they would
-// otherwise spend waiting for wave 0 at the phase's barrier (wave 3 has nothing else to do at kb = 2): the persistent
-// schedule fetches the next panel's tiles there.  It must not touch A, X or T.
+// otherwise spend waiting for wave 0 at the phase's barrier (they have nothing at all to do at kb = 0, wave 3 nothing at
+// kb = 2): the persistent schedule finishes its look-ahead update at kb = 0 (it may write the 16x16 sub-tiles (i, j),
+// 1 <= j <= i <= 3, of A: nothing in step 0's factor phase reads or writes them) and fetches the next panel's tiles at
+// kb >= 2 (kb = 4 stands for the routine's tail, where waves 1..3 wait for wave 0's last inverse pair).  Apart from that
+// it must not touch A, X or T.
 template <int VAR, bool STAMP, class Hook = NoHook>
 __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__restrict__ X, double *__restrict__ T, int p,
                                           int *__restrict__ info, unsigned long long *__restrict__ stamps,
@@ -177,6 +180,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
         for (int k = 0; k < 16; ++k) A[(o + lr) * DLD + o + k] = (k <= lr) ? a[k] : 0.0;
       }
     }
+    if (VAR >= 1 && wave > 0 && kb == 0) hook(0, wave);  // waves 1..3 have nothing of their own to do in step 0
     if (VAR >= 1 && wave > 0 && kb > 0) {
       // while wave 0 factors: the previous step's update of the tiles right of block column kb, with the previous
       // step's panel (columns o - 16 ..).  kb = 1: (2,2) (3,2) (3,3); kb = 2: (3,3) again with panel 1; kb = 3: none.
@@ -298,6 +302,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
 
   // What is left of the inverse doubling (VAR 1 did the pair (0,1) and T = L[32:64,0:32] X[0:32,0:32] inside the
   // loop, on waves that were idle): the pair (2,3), then X[32:64, 0:32] = -X[32:64, 32:64] * T.
+  if (VAR >= 1 && wave > 0) hook(4, wave);  // waves 1..3 wait for wave 0's pair (2,3) here
   if (VAR >= 1 ? wave == 0 : wave < 2) {
     const int a0 = (VAR >= 1 ? 1 : wave) * 32, c0 = a0 + 16;
     d4_t t = {0.0, 0.0, 0.0, 0.0};

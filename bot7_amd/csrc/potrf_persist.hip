@@ -242,6 +242,50 @@ struct Prefetch {
   double *S1, *S2;
   int *done;  // LDS: [0] tile below in S1, [1] / [2] upper / lower half of the next diagonal tile in S2
   int p;
+  double *A;     // the block being factored: step 0's hook completes its lower sub-tiles right of column block 0
+  int *pub_cnt;  // LDS: waves that have drained their stores of this round; the fourth raises ready(p, p-1)
+
+  // Step 0 of panel p's factorisation, waves 1..3 (wave 0 is factoring sub-block 0 and solving column block 0):
+  // the part of the look-ahead that wave 0 does not need yet.  (1) C(p, p) -= L[p][p-1] L[p][p-1]' on the six sub-tiles
+  // (i, j), 1 <= j <= i <= 3, two per wave as interleaved 64-deep chains from zero, then the subtraction; (2) L[p][p-1]
+  // goes out write-through; (3) drained, counted in LDS, and the last of the four waves raises its flag.
+  __device__ __forceinline__ void finish_lookahead(int wave) const {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4, n = a.n;
+    // L[p][p-1] from its LDS image first (192 lanes): the write-through stores drain under the MFMAs below
+    {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(a.L + ((int64_t)p * NB) * n + (int64_t)(p - 1) * NB);
+      const int t = threadIdx.x - 64;
+#pragma unroll
+      for (int i = 0; i < 11; ++i) {
+        const int c = t + 192 * i;
+        if (c < 2048) {
+          const int row = c >> 5, col = 2 * (c & 31);
+          st16_sc1(rs, (row * n + col) * 8, *reinterpret_cast<const d2_t *>(S1 + row * DLD + col));
+        }
+      }
+    }
+    // wave 1: (1,1) (2,1)   wave 2: (3,1) (2,2)   wave 3: (3,2) (3,3)
+    const int s0 = wave == 1 ? 1 : 3, c0 = wave == 3 ? 2 : 1, s1 = wave == 3 ? 3 : 2, c1 = wave == 1 ? 1 : (wave == 2 ? 2 : 3);
+    d4_t u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
+    const double *a0 = S1 + (16 * s0 + lr) * DLD + lq, *b0 = S1 + (16 * c0 + lr) * DLD + lq;
+    const double *a1 = S1 + (16 * s1 + lr) * DLD + lq, *b1 = S1 + (16 * c1 + lr) * DLD + lq;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      u0 = mfma_f64(a0[4 * k4], b0[4 * k4], u0);
+      u1 = mfma_f64(a1[4 * k4], b1[4 * k4], u1);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int e0 = (16 * s0 + lq + 4 * rr) * DLD + 16 * c0 + lr, e1 = (16 * s1 + lq + 4 * rr) * DLD + 16 * c1 + lr;
+      A[e0] = S2[e0] - u0[rr];
+      A[e1] = S2[e1] - u1[rr];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // issued ~1 us ago
+    if (lane == 0) {
+      const int before = __hip_atomic_fetch_add(pub_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (before == 3) st_flag(F.ready(p, p - 1), 1u);
+    }
+  }
   __device__ __forceinline__ void rows(const double *src, bool plain, double *img, int row0, int nrows, int tile,
                                        bool diag) const {
     const int lane = threadIdx.x & 63, n = a.n;
@@ -265,8 +309,12 @@ struct Prefetch {
     }
   }
   __device__ __forceinline__ void operator()(int kb, int wave) const {
+    if (kb == 0) {
+      if (p > 0) finish_lookahead(wave);
+      return;
+    }
     // panel 0's neighbours come straight from K (cold in HBM: the blocking path after the factorisation is faster)
-    if (kb < 2 || p == 0 || p + 1 >= a.nb) return;
+    if (kb < 2 || p == 0 || p + 1 >= a.nb) return;  // kb = 2, 3 and the tail (4)
     const int n = a.n, lane = threadIdx.x & 63;
     if (wave == 3) {
       if (done[0] != 0 || ld_flag(F.pre_sub(p + 1)) == 0u) return;
@@ -280,13 +328,7 @@ struct Prefetch {
   }
 };
 
-// the ten 16x16 sub-tiles (slab s, column block cb), cb <= s, of the next diagonal block, three / three / two / two to
-// a wave; the six above the diagonal are never read by the factor routine and keep whatever the last round left there
-__device__ constexpr int SUB_N[4] = {3, 3, 2, 2};
-__device__ constexpr int SUB_S[4][3] = {{0, 1, 2}, {3, 1, 2}, {3, 2, 0}, {3, 3, 0}};
-__device__ constexpr int SUB_C[4][3] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 0}, {2, 3, 0}};
-
-__device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *sh_ok, int *pf_done) {
+__device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *sh_ok, int *pf_done, int *pub_cnt) {
   int turn = 0;
   double *A = dsm, *X = dsm + NB * DLD, *T = X + NB * DLD, *S1 = T + 32 * TLD, *S2 = S1 + NB * DLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15,
@@ -311,12 +353,21 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
   __syncthreads();
   for (int p = 0; p < nb; ++p) {
     PST(p, 0);
-    diag_core<1, false>(A, X, T, p, a.info, nullptr, Prefetch{a, F, S1, S2, pf_done, p});
+    diag_core<1, false>(A, X, T, p, a.info, nullptr, Prefetch{a, F, S1, S2, pf_done, p, A, pub_cnt});
     PST(p, 1);
     const bool last = p + 1 == nb;
     const bool have_d1 = pf_done[0] != 0, have_d2 = pf_done[1] != 0 && pf_done[2] != 0;
+    // inv(L_pp) first and by itself: it is what every helper of this panel waits for (nobody inside the launch reads L_pp),
+    // and the sooner its flag is up the sooner the next panel's tiles come back.  The drain costs this workgroup ~0.5 us.
+    {
+      d2_t vx[8];
+      tile_from_lds(vx, X);
+      tile_store_sc1(vx, a.dinv + (int64_t)p * NB * NB, NB);
+    }
+    if (p != a.fault_panel) wg_publish(F.ready(p, p));
+    PST(p, 2);
     d2_t d1[8], d2[8];
-    // what the prefetch did not get, first (its latency overlaps the stores of L_pp and inv(L_pp) issued behind it)
+    // what the prefetch did not get (its latency overlaps the store of L_pp issued behind it)
     if (!last && p == 0) {
       tile_load_plain(d1, a.K + (int64_t)NB * n, n);
       tile_load_plain(d2, a.K + (int64_t)NB * n + NB, n);
@@ -327,11 +378,9 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       if (!have_d1) tile_load_sc1(d1, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
       if (!have_d2) tile_load_sc1(d2, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)(p + 1) * NB, n);
     }
-    PST(p, 2);
-    {  // L_pp (upper triangle zeroed) and inv(L_pp), write-through
-      d2_t va[8], vx[8];
+    {  // L_pp, upper triangle zeroed
+      d2_t va[8];
       tile_from_lds(va, A);
-      tile_from_lds(vx, X);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = tid + 256 * i, row = c >> 5, col = 2 * (c & 31);
@@ -339,17 +388,17 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
         if (col + 1 > row) va[i][1] = 0.0;
       }
       tile_store_sc1(va, a.L + ((int64_t)p * NB) * n + (int64_t)p * NB, n);
-      tile_store_sc1(vx, a.dinv + (int64_t)p * NB * NB, NB);
     }
     if (last) {
-      wg_publish(F.ready(p, p));
       PST(p, 7);  // exit
+      if (st && tid == 0) st[p * 8 + 5] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same counter on every CU
       break;
     }
     if (!have_d1) tile_to_lds(d1, S1);
     if (!have_d2) tile_to_lds(d2, S2);
     __syncthreads();  // also: everybody has read pf_done
     if (tid < 4) pf_done[tid] = 0;
+    if (tid == 4) *pub_cnt = 0;
     PST(p, 3);
     // L[p+1][p] = C inv(L_pp)': wave w rows 16 w .., all four column blocks; the chain of potrf_trsm_kernel<NEAR>
     // (k ascending, whole 16-blocks above the diagonal of inv(L_pp) skipped)
@@ -384,46 +433,33 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       for (int jb = 0; jb < 4; ++jb) S1[(wave * 16 + lq + 4 * rr) * DLD + jb * 16 + lr] = lqv[jb][rr];
     __syncthreads();
     PST(p, 4);
-    // L_pp and inv(L_pp) were issued a triangular solve ago: the drain inside the publish is (nearly) free by now
-    if (p != a.fault_panel) wg_publish(F.ready(p, p));
-    {
-      d2_t vl[8];
-      tile_from_lds(vl, S1);
-      tile_store_sc1(vl, a.L + ((int64_t)(p + 1) * NB) * n + (int64_t)p * NB, n);
-    }
     PST(p, 5);
-    // C(p+1, p+1) -= L[p+1][p] L[p+1][p]': per 16x16 sub-tile the 64-deep chain from zero, then the subtraction
-    // (syrk_tile / NEAR update); this wave's sub-tiles run as interleaved chains
+    // The next factorisation's first step needs column block 0 of C(p+1, p+1) only (wave 0 factors sub-block (0, 0) and
+    // solves the three below it in the same instruction stream): wave w applies the update to sub-tile (w, 0) now -- the
+    // 64-deep chain from zero, then the subtraction (syrk_tile / NEAR update) -- and waves 1..3 do the other six lower
+    // sub-tiles, the store of L[p+1][p] and its flag inside that first step, where they would otherwise idle
+    // (Prefetch::finish_lookahead).  The six sub-tiles above the diagonal are never read by the factor routine.
     {
-      d4_t u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0}, u2 = {0.0, 0.0, 0.0, 0.0};
-      const int nsub = SUB_N[wave];
-      const int s0 = SUB_S[wave][0], s1 = SUB_S[wave][1], s2 = SUB_S[wave][2];
-      const int c0 = SUB_C[wave][0], c1 = SUB_C[wave][1], c2 = SUB_C[wave][2];
-      const double *a0 = S1 + (16 * s0 + lr) * DLD + lq, *a1 = S1 + (16 * s1 + lr) * DLD + lq, *a2 = S1 + (16 * s2 + lr) * DLD + lq;
-      const double *b0 = S1 + (16 * c0 + lr) * DLD + lq, *b1 = S1 + (16 * c1 + lr) * DLD + lq, *b2 = S1 + (16 * c2 + lr) * DLD + lq;
-      double pa0 = a0[0], pa1 = a1[0], pa2 = a2[0], pb0 = b0[0], pb1 = b1[0], pb2 = b2[0];
+      d4_t u = {0.0, 0.0, 0.0, 0.0};
+      const double *ar = S1 + (16 * wave + lr) * DLD + lq, *br = S1 + lr * DLD + lq;
 #pragma unroll
-      for (int k4 = 0; k4 < 16; ++k4) {  // next step's operands in flight under this step's MFMAs
-        const int kn = k4 + 1 < 16 ? 4 * (k4 + 1) : 0;
-        const double na0 = a0[kn], na1 = a1[kn], na2 = a2[kn], nb0 = b0[kn], nb1 = b1[kn], nb2 = b2[kn];
-        u0 = mfma_f64(pa0, pb0, u0);
-        u1 = mfma_f64(pa1, pb1, u1);
-        u2 = mfma_f64(pa2, pb2, u2);  // waves 2 and 3: a spare chain, dropped below
-        pa0 = na0, pa1 = na1, pa2 = na2, pb0 = nb0, pb1 = nb1, pb2 = nb2;
-      }
+      for (int k4 = 0; k4 < 16; ++k4) u = mfma_f64(ar[4 * k4], br[4 * k4], u);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int e0 = (16 * s0 + lq + 4 * rr) * DLD + 16 * c0 + lr, e1 = (16 * s1 + lq + 4 * rr) * DLD + 16 * c1 + lr,
-                  e2 = (16 * s2 + lq + 4 * rr) * DLD + 16 * c2 + lr;
-        A[e0] = S2[e0] - u0[rr];
-        A[e1] = S2[e1] - u1[rr];
-        if (nsub > 2) A[e2] = S2[e2] - u2[rr];
+        const int e = (16 * wave + lq + 4 * rr) * DLD + lr;
+        A[e] = S2[e] - u[rr];
       }
     }
-    __syncthreads();
-    put_identity_corner(A);
+    put_identity_corner(A);  // rows 0..15 x columns 48..63: above the diagonal, nobody else writes there
     PST(p, 6);
-    wg_publish(F.ready(p + 1, p));  // its barrier also orders the corner before the factor's first reads
+    if (wave == 0) {  // this wave's stores of L_pp / inv(L_pp) have long drained; it is the fourth party to the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const int before = __hip_atomic_fetch_add(pub_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (before == 3) st_flag(F.ready(p + 1, p), 1u);
+      }
+    }
+    __syncthreads();  // column block 0 and the corner are in place
     PST(p, 7);
   }
 #undef PST
@@ -495,24 +531,30 @@ __device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J,
     tile_load_sc1(vx, a.dinv + (int64_t)J * NB * NB, NB);
     tile_to_lds(vx, Xp);
     __syncthreads();
-    // L_IJ = C inv(L_JJ)': slab s rows 16 s .., wave w column block w, k-blocks above the diagonal skipped
-    d4_t li[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    // L_IJ = C inv(L_JJ)': sub-tile (slab s, column block cb) is a chain over the k-blocks 0 .. cb (those above the
+    // diagonal of inv(L_JJ) are skipped), i.e. 4 (cb + 1) MFMAs; the sixteen sub-tiles are dealt so that every wave
+    // issues 40:  wave 0: (0,3) (1,3) (0,1)   wave 1: (2,3) (3,3) (1,1)   wave 2: (0,2) (1,2) (2,2) (0,0)
+    // wave 3: (3,2) (2,1) (3,1) (1,0) (2,0) (3,0)
+    constexpr int TS_N[4] = {3, 3, 4, 6};
+    constexpr int TS_S[4][6] = {{0, 1, 0, 0, 0, 0}, {2, 3, 1, 0, 0, 0}, {0, 1, 2, 0, 0, 0}, {3, 2, 3, 1, 2, 3}};
+    constexpr int TS_C[4][6] = {{3, 3, 1, 0, 0, 0}, {3, 3, 1, 0, 0, 0}, {2, 2, 2, 0, 0, 0}, {2, 1, 1, 0, 0, 0}};
+    d4_t li[6];
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-      if (kq > wave) break;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int ko = kq * 16 + 4 * s4 + lq;
-        const double xb = Xp[(wave * 16 + lr) * DLD + ko];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) li[s] = mfma_f64(Ai[(16 * s + lr) * DLD + ko], xb, li[s]);
-      }
+    for (int t = 0; t < 6; ++t) {
+      li[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+      if (t >= TS_N[wave]) continue;
+      const int sl = TS_S[wave][t], cb = TS_C[wave][t];
+      const double *ar = Ai + (16 * sl + lr) * DLD + lq, *xr = Xp + (16 * cb + lr) * DLD + lq;
+      for (int k4 = 0; k4 < 4 * (cb + 1); ++k4) li[t] = mfma_f64(ar[4 * k4], xr[4 * k4], li[t]);
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int t = 0; t < 6; ++t) {
+      if (t >= TS_N[wave]) continue;
+      const int sl = TS_S[wave][t], cb = TS_C[wave][t];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Ai[(16 * s + lq + 4 * rr) * DLD + wave * 16 + lr] = li[s][rr];
+      for (int rr = 0; rr < 4; ++rr) Ai[(16 * sl + lq + 4 * rr) * DLD + cb * 16 + lr] = li[t][rr];
+    }
   }
   __syncthreads();
   d2_t vo[8];
@@ -644,10 +686,12 @@ __device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok, 
     if (part == 0) {
       z[p * 64 + row] = sz;
       ssq += sz * sz;
+      // log L_ii = -log inv(L_pp)_ii: the diagonal of a triangular inverse is the reciprocal diagonal (L_pp itself is
+      // not behind a flag)
       const unsigned long long bits = __hip_atomic_load(
-          reinterpret_cast<const unsigned long long *>(a.L + ((int64_t)p * NB + row) * n + (int64_t)p * NB + row),
-          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      logdet += log(__longlong_as_double((long long)bits));
+          reinterpret_cast<const unsigned long long *>(a.dinv + (int64_t)p * NB * NB + row * NB + row), __ATOMIC_RELAXED,
+          __HIP_MEMORY_SCOPE_AGENT);
+      logdet -= log(__longlong_as_double((long long)bits));
     }
     __syncthreads();
   }
@@ -670,7 +714,7 @@ __device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok, 
 
 __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
   extern __shared__ __align__(16) double dsm[];
-  __shared__ int sh_ok[2], sh_job, pf_done[4];
+  __shared__ int sh_ok[2], sh_job, pf_done[4], pub_cnt;
   {
     const int64_t b = blockIdx.y;  // one factorisation per grid row
     a.K += b * a.sK;
@@ -685,7 +729,7 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
   }
   const Flags F{a.flags, a.nb};
   if (blockIdx.x == 0) {
-    critical_path(a, F, dsm, sh_ok, pf_done);
+    critical_path(a, F, dsm, sh_ok, pf_done, &pub_cnt);
     return;
   }
   const int n = a.n;
@@ -723,7 +767,7 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
       tile_store_plain(z, a.L + ((int64_t)I * NB) * n + (int64_t)J * NB, n);
       if (a.with_inverse) tile_store_plain(z, a.Linv + ((int64_t)I * NB) * n + (int64_t)J * NB, n);
     }
-    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 4 + 1] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && threadIdx.x == 0) a.stamps[a.nb * 8 + jid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     if (!ok) return;
   }
 }
@@ -749,7 +793,10 @@ static int persist_jobs(b7_ctx *c, int nb, int mode, const int4 **jobs_dev, int 
     for (int p = 2; p < nb; ++p) jobs.push_back({JOB_PRE_DIAG, p, p, (p - 1) - 0.55});
     if (mode == 1) {
       for (int p = 1; p < nb; ++p)
-        for (int j = 0; j < p; ++j) jobs.push_back({JOB_INV, p, j, p + 0.5 + 0.001 * (p - j)});
+        // a tile of row p with many products (small j) is popped up to ~1.4 panels ahead of the light ones: popped late
+        // it would still be catching up on its p - j products when the factorisation is over.  0.045 (p - j) < 1.5 keeps
+        // every L[p][t], t < p (key < p - 1 + 0.04) ahead of it in the queue
+        for (int j = 0; j < p; ++j) jobs.push_back({JOB_INV, p, j, p + 0.5 - 0.045 * (p - j)});
       for (int p = 0; p < nb; ++p) jobs.push_back({JOB_INV_DIAG, p, p, p + 0.9});
     }
     if (mode == 2) {
@@ -783,8 +830,13 @@ static int persist_launch(b7_ctx *c, PArgs a, int B, int mode, int helpers) {
     c->persist_attr_set = true;
   }
   B7_TRY(persist_jobs(c, a.nb, mode, &a.jobs, &a.njobs));
-  B7_HIP(c, hipMemsetAsync(a.flags, 0, sizeof(unsigned) * (B > 1 ? (size_t)a.sflags * B : persist_flag_words(a.nb)), c->stream));
-  B7_HIP(c, hipMemsetAsync(a.info, 0, sizeof(int) * (B > 1 ? (size_t)a.sinfo * B : 4), c->stream));
+  if (reinterpret_cast<char *>(a.flags) == reinterpret_cast<char *>(a.info) + B7_INFO_HEAD_BYTES && B == 1) {
+    // the single fit: info, likelihood terms and flags are one block (b7_internal.h) -> one memset node
+    B7_HIP(c, hipMemsetAsync(a.info, 0, B7_INFO_HEAD_BYTES + sizeof(unsigned) * persist_flag_words(a.nb), c->stream));
+  } else {
+    B7_HIP(c, hipMemsetAsync(a.flags, 0, sizeof(unsigned) * (B > 1 ? (size_t)a.sflags * B : persist_flag_words(a.nb)), c->stream));
+    B7_HIP(c, hipMemsetAsync(a.info, 0, sizeof(int) * (B > 1 ? (size_t)a.sinfo * B : 4), c->stream));
+  }
   a.with_inverse = mode == 1 ? 1 : 0;
   hipLaunchKernelGGL(potrf_persist_kernel, dim3(1 + helpers, B), dim3(256), PERSIST_LDS_BYTES, c->stream, a);
   B7_HIP(c, hipGetLastError());
@@ -796,14 +848,15 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
   PhaseScope ps(c, "potrf");
   const int n = c->Npad, nb = n / NB, mode = with_inverse ? 1 : 0;
   c->linv_done = false;
-  B7_TRY(b7_ensure(c, c->pflags, sizeof(unsigned) * persist_flag_words(nb)));
+  static_assert(FLAG_HDR + 2 * 32 * 32 + 2 * 32 == B7_PERSIST_FLAG_WORDS_MAX, "flag block of the largest persistent shape");
+  B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
   PArgs a = {};
   a.fault_panel = c->persist_fault;
   a.K = (const double *)c->K.p;
   a.L = (double *)c->L.p;
   a.Linv = with_inverse ? (double *)c->Linv.p : nullptr;
   a.dinv = (double *)c->dinv.p;
-  a.flags = (unsigned *)c->pflags.p;
+  a.flags = reinterpret_cast<unsigned *>(static_cast<char *>(c->info.p) + B7_INFO_HEAD_BYTES);
   a.info = (int *)c->info.p;
   a.n = n;
   a.nb = nb;

@@ -1,8 +1,9 @@
 """Where the persistent Cholesky's critical workgroup spends its time, and when the helper jobs run (s_memtime stamps,
 B7_PERSIST_STAMPS=1).   python tools/persist_stamps.py [N]
 Critical path per panel p (cycles of the 100 MHz... no: s_memtime ticks = shader cycles at ~2.4 GHz under light load):
-  0 factor start | 1 factor end | 2 tile-below load issued (after its flag) | 3 tile in LDS | 4 trsm done |
-  5 next diagonal block loaded (after its flag) | 6 update done | 7 published"""
+  0 factor start | 1 factor end (waves 1..3 finish the previous look-ahead inside its first step) | 2 both next tiles
+  waited for / issued | 3 L_pp, inv(L_pp) stored, tiles in LDS | 4 triangular solve done | 5 inv(L_pp) published |
+  6 column block 0 of the next diagonal block updated | 7 barrier"""
 import ctypes as C
 import os
 import sys
@@ -32,7 +33,7 @@ crit = buf[:nb * 8].reshape(nb, 8).astype(np.int64)
 jobs = buf[nb * 8:nb * 8 + nj * 4].reshape(nj, 4).astype(np.int64)
 t0 = crit[0, 0]
 GHZ = 2.4
-names = ["factor", "wait+issue D1", "stores+D1->LDS", "trsm", "wait+load D2", "update", "publish"]
+names = ["factor(+rest)", "publish inv", "tiles+store L", "trsm", "-", "col-0 update", "barrier"]
 print("panel  start_us  " + "  ".join("%-14s" % s for s in names) + "  total_us")
 tot = np.zeros(7)
 for p in range(nb):
@@ -46,6 +47,11 @@ print("mean   %8s  " % "" + "  ".join("%-14.2f" % v for v in tot / (nb - 1)))
 print("critical path total %.1f us (first factor start -> last factor end)" % ((crit[nb - 1, 1] - t0) / GHZ / 1e3))
 print("workgroup 0: entry -> first factor %.1f us; last factor end -> exit %.1f us; entry -> exit %.1f us" % (
     (t0 - crit[nb - 1, 6]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 1]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 6]) / GHZ / 1e3))
+# job ends and workgroup 0's exit on the 100 MHz real-time counter (comparable across CUs)
+lag = (jobs[:, 1] - crit[nb - 1, 5]) / 100.0
+late = np.argsort(-lag)[:8]
+print("helper jobs still running after workgroup 0 left: %d; the last ends %.1f us later; latest job ids %s (lag us %s)" % (
+    int((lag > 0).sum()), lag.max(), late.tolist(), np.round(lag[late], 1).tolist()))
 upd = jobs[jobs[:, 3] > 0]
 flop = float(upd[:, 3].sum()) * 2 * 64 ** 3
 secs = float(upd[:, 2].sum()) / (GHZ * 1e9)
