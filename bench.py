@@ -228,8 +228,7 @@ def main():
         else:
             for s_i in range(samples):        # bots/bayesopt.lua:73-78: one fit + predict + score:add per hyper sample
                 scale = 1.0 + 0.05 * s_i      # distinct hypers per sample, as a sampler would hand over
-                ctx.gp_fit_hyp(hyp["lenscale_sq"] * scale, hyp["amp"], hyp["noise"], hyp["mean"])
-                ctx.gp_predict(download=False)
+                ctx.gp_predict_hyp(hyp["lenscale_sq"] * scale, hyp["amp"], hyp["noise"], hyp["mean"])  # fit + predict
                 if s_i == 0:
                     ctx.score_reset()
                 score_add()

@@ -19,7 +19,7 @@ ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove", "b7_grid_remove_rows",
-    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
+    "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_predict_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
     "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global",
     "b7_ei_compute", "b7_cb_compute", "b7_argmax",
@@ -94,6 +94,7 @@ def load():
         "b7_gp_fit": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(Hyp), vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_gp_set_data": (i32, [vp, vp, vp, i32, i32, i32]),
         "b7_gp_fit_hyp": (i32, [vp, C.POINTER(Hyp), vp, C.POINTER(dbl), C.POINTER(i32)]),
+        "b7_gp_predict_hyp": (i32, [vp, C.POINTER(Hyp), vp, vp, vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_gp_nll_batch": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "b7_chol": (i32, [vp, vp, i32, vp, C.POINTER(dbl), C.POINTER(i32)]),
         "b7_gp_predict": (i32, [vp, vp, vp]),
@@ -300,6 +301,27 @@ class Context(object):
         self._ck(self._L.b7_gp_fit_hyp(self._h, C.byref(hyp), _ptr(nll), C.byref(jit), C.byref(info)))
         self.fit_token += 1
         return {"nll": nll, "jitter": jit.value, "info": info.value}
+
+    def gp_predict_hyp(self, lenscale_sq, amp, noise, mean, download=False, want_nll=False):
+        """Fit the resident data under the hypers AND predict over the resident grid in one call (no host round trip
+        between the two).  Returns the fit report (+ mean, var when download)."""
+        ls = _f64(lenscale_sq).ravel()
+        if ls.size != getattr(self, "_data_d", -1):
+            raise Bot7HipError(-1, "lenscale_sq must have d entries (call gp_set_data first)")
+        hyp = Hyp(ls.ctypes.data_as(C.POINTER(C.c_double)), float(amp), float(noise), float(mean))
+        nll = np.empty(self.ycols, dtype=np.float64) if want_nll else None
+        jit, info = C.c_double(), C.c_int()
+        mu = var = None
+        if download:
+            M, _ = self.grid_shape()
+            mu, var = np.empty((M, self.ycols), dtype=np.float64), np.empty(M, dtype=np.float64)
+        self._ck(self._L.b7_gp_predict_hyp(self._h, C.byref(hyp), _ptr(mu), _ptr(var), _ptr(nll), C.byref(jit),
+                                           C.byref(info)))
+        self.fit_token += 1
+        out = {"nll": nll, "jitter": jit.value, "info": info.value}
+        if download:
+            out["mean"], out["var"] = mu, var
+        return out
 
     def gp_nll_batch(self, lenscale_sq, amp, noise, mean, want_info=False):
         """Negative log marginal likelihoods of the resident data (gp_set_data) under B hyper vectors at once."""

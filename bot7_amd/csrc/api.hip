@@ -143,6 +143,7 @@ int b7_create(b7_ctx **out, int device_id) {
     if (g >= 1 && g <= 8) c->potrf_group = g;
   }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fit, hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 16384, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0);
   if (e != hipSuccess) {
@@ -181,6 +182,7 @@ void b7_destroy(b7_ctx *c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
+  if (c->ev_fit) (void)hipEventDestroy(c->ev_fit);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -409,7 +411,13 @@ int b7_gp_set_data(b7_ctx *c, const double *X, const double *Y, int N, int d, in
   return B7_OK;
 }
 
-int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info_out) {
+static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, double *var);
+
+// then_predict: the posterior over the resident grid is enqueued right behind the fit, before the host has seen the
+// pivot report, and the host only waits for the report (an event), not for the prediction.  If the report says the
+// plain attempt failed (rare), the speculative prediction is thrown away and redone after the jitter schedule.
+static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info_out,
+                        bool then_predict) {
   if (!c) return B7_ERR_INVALID;
   if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "gp_fit_hyp: call b7_gp_set_data first");
   if (!hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit_hyp: NULL argument");
@@ -459,8 +467,16 @@ int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_
       if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
     }
     B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, tail_done ? blk_bytes : 16, hipMemcpyDeviceToHost, c->stream));
-    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (then_predict && tail_done) {
+      B7_HIP(c, hipEventRecord(c->ev_fit, c->stream));
+      c->fitted = true;  // for the launchers; withdrawn below if the report says otherwise
+      B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
+      B7_HIP(c, hipEventSynchronize(c->ev_fit));
+    } else {
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+    }
     if (blk.info[1] == 0) break;
+    c->fitted = false;
     // the persistent schedule gave up on a hand-off (its workgroups were not all resident, e.g. the GPU is shared
     // with another process's persistent kernel): same arithmetic through the launch schedule, which cannot stall
     if (attempt == 1) return b7_fail(c, B7_ERR_HIP, "Cholesky: hand-off time-out (code %d) outside the persistent schedule", blk.info[1]);
@@ -468,9 +484,12 @@ int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_
   }
   const int info_first = blk.info[0];
   double jitter = 0.0;
+  bool predicted = then_predict && tail_done;
   if (info_first != 0) {
+    c->fitted = false;
     B7_TRY(jitter_retries(c, &jitter, true));
     tail_done = false;
+    predicted = false;
   }
   if (!tail_done) {
     B7_TRY(launch_trtri(c));
@@ -478,6 +497,10 @@ int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_
     if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
     B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, blk_bytes, hipMemcpyDeviceToHost, c->stream));
     B7_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  if (then_predict && !predicted) {
+    c->fitted = true;
+    B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
   }
   if (nll_out)
     for (int k = 0; k < ycols; ++k) nll_out[k] = 0.5 * blk.terms[1 + k] + blk.terms[0] + 0.5 * N * log(2.0 * M_PI);
@@ -587,6 +610,31 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     if (jitter_out) jitter_out[b] = jitter;
     if (info_out) info_out[b] = info_first;
   }
+  return B7_OK;
+}
+
+int b7_gp_fit_hyp(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info_out) {
+  return fit_hyp_core(c, hyp, nll_out, jitter_used, info_out, false);
+}
+
+int b7_gp_predict_hyp(b7_ctx *c, const b7_hyp *hyp, double *mean_host, double *var_host, double *nll_out,
+                      double *jitter_used, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "gp_predict_hyp: call b7_gp_set_data first");
+  if (c->M <= 0) return b7_fail(c, B7_ERR_STATE, "gp_predict_hyp: no candidate grid on this context");
+  if (c->d != c->dfit) return b7_fail(c, B7_ERR_INVALID, "gp_predict_hyp: grid dims %d != data dims %d", c->d, c->dfit);
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M * c->ycols));
+  B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
+  B7_TRY(fit_hyp_core(c, hyp, nll_out, jitter_used, info_out, true));
+  c->predicted = true;
+  c->Mpred = c->M;
+  if (mean_host)
+    B7_HIP(c, hipMemcpyAsync(mean_host, c->mu.p, sizeof(double) * (size_t)c->M * c->ycols, hipMemcpyDeviceToHost,
+                             c->stream));
+  if (var_host)
+    B7_HIP(c, hipMemcpyAsync(var_host, c->var.p, sizeof(double) * (size_t)c->M, hipMemcpyDeviceToHost, c->stream));
+  if (mean_host || var_host) B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
 }
 

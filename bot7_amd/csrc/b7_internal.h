@@ -39,6 +39,7 @@ struct PhaseStat {
 struct b7_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev_fit = nullptr;  // behind the fit report's copy: b7_gp_predict_hyp waits for it, not for the prediction
   std::string err;
   int cus = 0;
 

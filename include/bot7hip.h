@@ -129,6 +129,14 @@ int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int 
 int b7_gp_set_data(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols);
 int b7_gp_fit_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info);
 
+/* model:predict(X_obs, Y_obs, X_hid, hyp, {mean, var}) in ONE call for resident data and a resident grid
+ * (scores/expected_improvement.lua:63 fits and predicts in one breath): b7_gp_fit_hyp + b7_gp_predict with the posterior
+ * enqueued right behind the fit, so the host waits for the pivot report only and never idles the GPU between the two
+ * (a failed plain attempt redoes the prediction after the jitter schedule).  Results as b7_gp_fit_hyp / b7_gp_predict;
+ * every output is nullable. */
+int b7_gp_predict_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *mean_host, double *var_host, double *nll_out,
+                      double *jitter_used, int *info);
+
 /* B likelihood evaluations of the resident data at once: the slice sampler's step-out / step-in probes
  * (samplers/slice.lua:118-164) and multi-chain samplers ask for the density at several hyper vectors per update.
  * lenscale_sq is B x d row-major; amp / noise / mean have B entries; nll_out[B] as b7_gp_fit_hyp's (same jitter schedule

@@ -34,6 +34,7 @@ int b7_gp_set_opts(b7_ctx *ctx, const b7_gp_opts *opts);
 int b7_gp_fit(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info);
 int b7_gp_set_data(b7_ctx *ctx, const double *X_obs, const double *Y_obs, int N, int d, int ycols);
 int b7_gp_fit_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *nll_out, double *jitter_used, int *info);
+int b7_gp_predict_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *mean_host, double *var_host, double *nll_out, double *jitter_used, int *info);
 int b7_gp_nll_batch(b7_ctx *ctx, int B, const double *lenscale_sq, const double *amp, const double *noise, const double *mean, double *nll_out, double *jitter_out, int *info_out);
 int b7_chol(b7_ctx *ctx, const double *src_host, int n, double *res_host, double *jitter_used, int *info);
 int b7_gp_predict(b7_ctx *ctx, double *mean_host, double *var_host);

@@ -1467,3 +1467,31 @@ def test_nll_batch_more_fits_than_fit_on_the_chip(ctx, orc):
         f = orc.gp.fit(X_obs, Y, hyp["lenscale_sq"] * scale[b], hyp["amp"], hyp["noise"], hyp["mean"])
         assert nll[b] == pytest.approx(float(f.nll[0]), rel=1e-9, abs=1e-7)
     assert np.all(np.diff(nll) != 0)
+
+
+def test_predict_hyp_is_fit_hyp_plus_predict(ctx, orc):
+    """b7_gp_predict_hyp (fit and posterior enqueued back to back, the host waits for the pivot report only) against the
+    two separate calls: same bits, with and without the jitter schedule kicking in after the speculative prediction."""
+    X_obs, Y, X_hid, hyp = make_problem(None, orc, 6, 300, 5000, B.hartmann6)
+    ctx.grid_upload(X_hid)
+    ctx.gp_set_data(X_obs, Y)
+    for h in (hyp, dict(hyp, lenscale_sq=hyp["lenscale_sq"] * 0.5, mean=hyp["mean"] + 0.2)):
+        a = ctx.gp_fit_hyp(want_nll=True, **h)
+        mu_a, var_a = ctx.gp_predict()
+        b = ctx.gp_predict_hyp(download=True, want_nll=True, **h)
+        assert np.array_equal(mu_a, b["mean"]) and np.array_equal(var_a, b["var"]) and a["nll"][0] == b["nll"][0]
+        assert (a["jitter"], a["info"]) == (b["jitter"], b["info"]) == (0.0, 0)
+        ctx.score_reset()
+        ctx.score_ei([float(Y.min())], 0.0)                 # scores run on the fused prediction
+        _, idx, ei = ctx.score_finish(1.0, download=True)
+        assert idx == orc.c.argmax_first(orc.c.ei(*orc.gp.predict(orc.gp.fit(X_obs, Y, **h), X_hid), [float(Y.min())]))[0]
+    Xd = X_obs.copy()
+    Xd[7] = Xd[3]
+    Yd = np.sin(3.0 * Xd).sum(axis=1, keepdims=True)
+    ctx.gp_set_data(Xd, Yd)
+    hj = dict(lenscale_sq=np.full(6, 0.4), amp=1.0, noise=0.0, mean=0.0)
+    a = ctx.gp_fit_hyp(**hj)
+    mu_a, var_a = ctx.gp_predict()
+    b = ctx.gp_predict_hyp(download=True, **hj)
+    assert a["jitter"] > 0 and (a["jitter"], a["info"]) == (b["jitter"], b["info"])
+    assert np.array_equal(mu_a, b["mean"]) and np.array_equal(var_a, b["var"])
