@@ -1485,11 +1485,12 @@ def test_predict_hyp_is_fit_hyp_plus_predict(ctx, orc):
         ctx.score_ei([float(Y.min())], 0.0)                 # scores run on the fused prediction
         _, idx, ei = ctx.score_finish(1.0, download=True)
         assert idx == orc.c.argmax_first(orc.c.ei(*orc.gp.predict(orc.gp.fit(X_obs, Y, **h), X_hid), [float(Y.min())]))[0]
-    Xd = X_obs.copy()
-    Xd[7] = Xd[3]
+    Xd = orc.c.sobol(300, 3, 1)
+    Xd[7] = Xd[3]                                            # a duplicate without noise: the plain attempt fails
     Yd = np.sin(3.0 * Xd).sum(axis=1, keepdims=True)
+    ctx.grid_upload(orc.c.sobol(3000, 3, 500))
     ctx.gp_set_data(Xd, Yd)
-    hj = dict(lenscale_sq=np.full(6, 0.4), amp=1.0, noise=0.0, mean=0.0)
+    hj = dict(lenscale_sq=np.full(3, 0.4), amp=1.0, noise=0.0, mean=0.0)
     a = ctx.gp_fit_hyp(**hj)
     mu_a, var_a = ctx.gp_predict()
     b = ctx.gp_predict_hyp(download=True, **hj)
