@@ -101,6 +101,8 @@ class gp_regressor(abstract):
         Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
         if self.hyp is None:
             self.init(X, Y)
+        if self.config.get("sample") and int(self.config.get("chains", 1)) > 1:
+            return self._sample_hypers_chains(X, Y, state)
         if self.config.get("sample"):
             from ..samplers import registry as Samplers
             if getattr(self, "_sampler", None) is None:
@@ -118,6 +120,104 @@ class gp_regressor(abstract):
             self.hyp = self._from_theta(theta)
         h = self.hyp
         return np.concatenate([h["lenscale_sq"], [h["amp"], h["noise"], h["mean"]]])
+
+    # ---- several chains in lock step: one b7_gp_nll_batch per round of density evaluations -------------------------------
+    def _sample_hypers_chains(self, X, Y, state):
+        """config.chains = C > 1: C independent slice-sampler chains (each the reference's sampler, statement for
+        statement, with its own random stream) advance TOGETHER: whenever every live chain has asked for a density
+        value, all the requests go to the device as one b7_gp_nll_batch.  The driver's per-sample calls
+        (bots/bayesopt.lua:74, state = true) are served one chain after the other, and a new lock-step update of all
+        chains runs whenever the C samples of the last one are used up; the call without `state` (:68) runs
+        config.nBurnin such updates.  A statistical variant of the reference's single chain (C chains of length k instead
+        of one of length C k), offered because at the sizes Bayesian optimisation lives in a batch of 16 likelihoods costs
+        what one does."""
+        C = int(self.config["chains"])
+        if getattr(self, "_chain_thetas", None) is None:
+            from ..samplers import registry as Samplers
+            self._sampler = Samplers[self.config.get("sampler", "slice")]()
+            self._sopt = self._sampler.configure(dict(self.config.get("sampler_opt") or {}))
+            self._sopt.setdefault("width", 0.5)
+            if self.config.get("noiseless") and self.hyp["noise"] <= 0.0:
+                self.hyp["noise"] = np.exp(self._bounds(X, Y)[0][-2])
+            t0 = self._to_theta(self.hyp)
+            seed = int(self.config.get("seed", 0))
+            self._chain_rngs = [np.random.default_rng([seed, c]) for c in range(C)]
+            # chain 0 starts at the point estimate, the others a little off it (inside the bounds)
+            lo, hi = self._bounds(X, Y)
+            self._chain_thetas = [np.clip(t0 + (0.1 * self._chain_rngs[c].standard_normal(t0.size) if c else 0.0), lo, hi)
+                                  for c in range(C)]
+            self._chain_pool = []
+        if not state:
+            for _ in range(int(self.config.get("nBurnin", 0))):
+                self._lockstep_update(X, Y)
+            self._chain_pool = []
+        else:
+            if not self._chain_pool:
+                self._lockstep_update(X, Y)
+                self._chain_pool = [t.copy() for t in self._chain_thetas]
+            self.hyp = self._from_theta(self._chain_pool.pop(0))
+        h = self.hyp
+        return np.concatenate([h["lenscale_sq"], [h["amp"], h["noise"], h["mean"]]])
+
+    def _lockstep_update(self, X, Y):
+        """One slice-sampler update of every chain, the density requests of all chains evaluated batch by batch."""
+        import threading
+        C, d = len(self._chain_thetas), X.shape[1]
+        lo, hi = self._bounds(X, Y)
+        key = (X.shape, Y.shape, float(X.sum()), float(Y.sum()))
+        if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
+            self.ctx.gp_set_data(X, Y)
+            self._resident_key = (key, self.ctx.fit_token)
+        cond = threading.Condition()
+        pending, results, alive, out, errors = {}, {}, [C], [None] * C, []
+
+        def density(c):
+            def f(t, _args):
+                t = np.asarray(t, dtype=np.float64).ravel()
+                if (t < lo).any() or (t > hi).any() or not np.isfinite(t).all():
+                    return -np.inf                      # flat prior inside the bounds: no device call
+                with cond:
+                    pending[c] = t
+                    cond.notify_all()
+                    while c not in results:
+                        cond.wait()
+                    return results.pop(c)
+            return f
+
+        def run(c):
+            try:
+                opt = dict(self._sopt, nSamples=1, rng=self._chain_rngs[c])
+                out[c] = self._sampler.sample(density(c), self._chain_thetas[c].reshape(1, -1), opt, None)[0]
+            except Exception as e:                      # surfaced by the caller
+                errors.append(e)
+            finally:
+                with cond:
+                    alive[0] -= 1
+                    cond.notify_all()
+
+        threads = [threading.Thread(target=run, args=(c,)) for c in range(C)]
+        for th in threads:
+            th.start()
+        with cond:
+            while alive[0] > 0:
+                while alive[0] > 0 and len(pending) < alive[0]:
+                    cond.wait()                         # until every live chain is waiting for a value
+                if not pending:
+                    break
+                ids = sorted(pending)
+                T = np.stack([pending[c] for c in ids])
+                pending.clear()
+                nll = self.ctx.gp_nll_batch(np.exp(T[:, :d]), np.exp(T[:, d]), np.exp(T[:, d + 1]), T[:, d + 2])
+                self.nEvals = getattr(self, "nEvals", 0) + len(ids)
+                self.nBatches = getattr(self, "nBatches", 0) + 1
+                for c, v in zip(ids, nll):
+                    results[c] = -float(v)
+                cond.notify_all()
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
+        self._chain_thetas = [np.asarray(o, dtype=np.float64) for o in out]
 
     @staticmethod
     def parse_hypers(vec):

@@ -1496,3 +1496,41 @@ def test_predict_hyp_is_fit_hyp_plus_predict(ctx, orc):
     b = ctx.gp_predict_hyp(download=True, **hj)
     assert a["jitter"] > 0 and (a["jitter"], a["info"]) == (b["jitter"], b["info"])
     assert np.array_equal(mu_a, b["mean"]) and np.array_equal(var_a, b["var"])
+
+
+def test_lockstep_chains_follow_the_single_chain_sampler_and_batch_their_densities(ctx, orc):
+    """config.chains = C: every chain is the reference's slice sampler with its own random stream; their density requests
+    go to the device as b7_gp_nll_batch calls.  Each chain must trace what the plain sampler traces when it is given
+    the same stream and start and evaluates its densities one b7_gp_fit_hyp at a time; and the C chains must need far
+    fewer device round trips than C times one chain."""
+    import time
+    import bot7_amd
+    X_obs, Y, _, hyp = make_problem(None, orc, 6, 200, 64, B.hartmann6)
+    C = 8
+    model = bot7_amd.models.gp_regressor({"sample": True, "chains": C, "nBurnin": 2, "seed": 3}, context=ctx)
+    model.hyp = dict(hyp)
+    model.sample_hypers(X_obs, Y)                                         # burn-in: two lock-step updates
+    t0 = time.perf_counter()
+    drawn = [model.parse_hypers(model.sample_hypers(X_obs, Y, None, None, True)) for _ in range(C)]
+    t_lock = time.perf_counter() - t0
+    evals, batches = model.nEvals, model.nBatches
+    assert batches < evals / 3, "the chains' requests were not batched (%d batches for %d evaluations)" % (batches, evals)
+    # the same update, chain by chain, through single fits
+    ref = bot7_amd.models.gp_regressor({"sample": True, "seed": 3}, context=ctx)
+    from bot7_amd.samplers import slice_sampler
+    S = slice_sampler()
+    lo, hi = model._bounds(X_obs, Y)
+    t0 = time.perf_counter()
+    for c in range(C):
+        # replay the chain's start, burn-in and update on a fresh stream seeded like the chain's own
+        rng = np.random.default_rng([3, c])
+        theta = np.clip(model._to_theta(hyp) + (0.1 * rng.standard_normal(9) if c else 0.0), lo, hi)   # d + 3 = 9
+        opt = dict(S.configure({"width": 0.5}), nSamples=1, rng=rng)
+        f = lambda t, _a: ref.log_posterior(t, X_obs, Y)  # noqa: E731
+        for _ in range(3):                                                # 2 burn-in updates + the sampled one
+            theta = S.sample(f, theta.reshape(1, -1), opt, None)[0]
+        got = model._to_theta(drawn[c])
+        assert np.allclose(got, theta, rtol=1e-7, atol=1e-9), "chain %d left the single-chain trajectory" % c
+    t_seq = time.perf_counter() - t0
+    print("8 chains, one update each: lock-step %.2f ms (%d likelihoods in %d batches); chain by chain incl. burn-in replay %.2f ms"
+          % (t_lock * 1e3, evals, batches, t_seq * 1e3))
