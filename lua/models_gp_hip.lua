@@ -123,8 +123,75 @@ function model:log_posterior(theta, X_obs, Y_obs)
   return -self:nll(X_obs, Y_obs, from_theta(theta))
 end
 
+-- config.chains = C > 1: C chains of the reference's own slice sampler advance in lock step.  Each chain runs inside a
+-- coroutine whose density function YIELDS the point it wants evaluated; when every live chain has yielded, all the
+-- points go to the device as one b7_gp_nll_batch and each coroutine is resumed with its value.  The sampler's code
+-- (samplers/slice.lua:51-168) runs unmodified.  Mirrors gp_regressor._lockstep_update of the Python harness.
+function model:lockstep_update(X_obs, Y_obs)
+  local C, d = #self.chains, X_obs:size(2)
+  local lo, hi = self:bounds(X_obs, Y_obs)
+  local co, waiting, nwait = {}, {}, 0
+  local function density(t, _)
+    local tv = t:view(-1)
+    if tv:lt(lo):any() or tv:gt(hi):any() or tv:ne(tv):any() then return -math.huge end   -- flat prior: no device call
+    return coroutine.yield(tv:clone())
+  end
+  local function step(c, value)
+    local ok, res = coroutine.resume(co[c], value)
+    if not ok then error(res) end
+    if coroutine.status(co[c]) == 'dead' then self.chains[c] = res; waiting[c] = nil
+    else waiting[c] = res; nwait = nwait + 1 end
+  end
+  for c = 1, C do
+    co[c] = coroutine.create(function()
+      return self.sampler.sample(density, self.chains[c]:view(1, -1), self.sopt, nil)[1]:clone()
+    end)
+    step(c, nil)
+  end
+  while nwait > 0 do
+    local ids, thetas = {}, torch.DoubleTensor(nwait, d + 3)
+    for c = 1, C do if waiting[c] then ids[#ids + 1] = c; thetas[#ids]:copy(waiting[c]) end end
+    local hyps = thetas:clone()
+    hyps:narrow(2, 1, d + 2):exp()                       -- theta = {log lenscale_sq, log amp, log noise, mean}
+    local nll = self:nll_batch(X_obs, Y_obs, hyps)
+    self.nEvals = self.nEvals + #ids
+    nwait = 0
+    for i, c in ipairs(ids) do step(c, -nll[i]) end
+  end
+end
+
+function model:sample_hypers_chains(X_obs, Y_obs, state)
+  local C = self.config.chains
+  if not self.chains then
+    local Samplers = require('bot7.samplers')
+    self.sampler = Samplers[self.config.sampler or 'slice']()
+    self.sopt    = self.sampler.configure(self.config.sampler_opt or {})
+    self.sopt.width, self.sopt.nSamples = self.sopt.width or 0.5, 1
+    local t0, lo, hi = to_theta(self.hyp), self:bounds(X_obs, Y_obs)
+    self.chains, self.pool = {}, {}
+    for c = 1, C do   -- chain 1 starts at the point estimate, the others a little off it (inside the bounds)
+      local t = t0:clone()
+      if c > 1 then t:add(0.1, torch.randn(t:nElement())):cmax(lo):cmin(hi) end
+      self.chains[c] = t
+    end
+  end
+  if not state then
+    for _ = 1, (self.config.nBurnin or 0) do self:lockstep_update(X_obs, Y_obs) end
+    self.pool = {}
+  else
+    if #self.pool == 0 then
+      self:lockstep_update(X_obs, Y_obs)
+      for c = 1, C do self.pool[c] = self.chains[c]:clone() end
+    end
+    self.hyp = from_theta(table.remove(self.pool, 1))
+  end
+  local h = self.hyp
+  return torch.cat(h.lenscale_sq, torch.DoubleTensor{h.amp, h.noise, h.mean})
+end
+
 function model:sample_hypers(X_obs, Y_obs, _, _, state) -- bots/bayesopt.lua:68 (burn-in) and :74 (state = true)
   if not self.hyp then self:init(X_obs, Y_obs) end
+  if self.config.sample and (self.config.chains or 1) > 1 then return self:sample_hypers_chains(X_obs, Y_obs, state) end
   if self.config.sample then
     local Samplers = require('bot7.samplers')
     if not self.sampler then

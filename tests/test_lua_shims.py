@@ -104,6 +104,8 @@ def test_shims_speak_the_driver_protocol():
     for meth in ("init", "sample_hypers", "parse_hypers", "predict", "fantasize", "nll", "predict_device"):
         assert re.search(r"function model:%s\(" % meth, gp), meth
     assert "bot7.samplers" in gp and "self.sampler.sample(" in gp and "log_posterior" in gp   # samplers/slice.lua drives nll
+    # several chains in lock step: the reference's sampler inside coroutines, densities through b7_gp_nll_batch
+    assert "coroutine.yield(" in gp and "coroutine.resume(" in gp and "self:nll_batch(X_obs, Y_obs, hyps)" in gp
     sc = strip_lua_comments(open(os.path.join(LUA, "scores_hip.lua")).read())
     assert re.search(r"model:fantasize\(config\.nFantasies,\s*X_obs,\s*Y_obs,\s*X_pend,\s*hyp\)", sc)
     assert "X_obs:cat(X_pend, 1)" in sc and "repeatTensor(1, config.nFantasies):cat(Y_pend, 1)" in sc
