@@ -161,11 +161,28 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     grouped = "RANK" in os.environ  # launched by torch.distributed.run: join the group even when it has one rank
+
+    class quiet_stdout(object):
+        """gloo and RCCL print banners on stdout when a group / communicator comes up: keep stdout for the one JSON
+        line by pointing fd 1 at stderr meanwhile."""
+
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+
+        def __exit__(self, *exc):
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+
     if grouped:
         # control plane only (rendezvous, the id hand-over, the barrier of the timing contract): a gloo group on the
         # CPU.  Every byte of the data path's one exchange goes through the C ABI.
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        td.init_process_group("gloo", rank=rank, world_size=world)
+        with quiet_stdout():
+            td.init_process_group("gloo", rank=rank, world_size=world)
+            td.barrier()
 
     import bot7_amd
     from bot7_amd import _lib, benchmarks, dist
@@ -178,19 +195,11 @@ def main():
     if args.workspace_mib:
         ctx.set_workspace(args.workspace_mib << 20)
     if grouped and rccl:
-        # RCCL prints a banner on stdout when a communicator comes up: keep stdout for the one JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with quiet_stdout():
             box = [_lib.comm_unique_id() if rank == 0 else None]
             td.broadcast_object_list(box, src=0)
             ctx.comm_init(rank, world, box[0])
             ctx.comm_allreduce([0.0])          # first collective: brings the rings up before anything is timed
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
 
     # ---- inputs, resident in HBM before the timed region
     shard = dist.ShardedScorer(ctx, M_total, rank, world)
