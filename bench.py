@@ -384,10 +384,12 @@ def main():
         line["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(line))
-    ctx.close()
-    if grouped:
-        td.barrier()
-        td.destroy_process_group()
+    sys.stdout.flush()
+    with quiet_stdout():   # nothing after the JSON line reaches stdout
+        ctx.close()
+        if grouped:
+            td.barrier()
+            td.destroy_process_group()
 
 
 if __name__ == "__main__":
