@@ -10,8 +10,11 @@
 // workgroups that wait on flags:
 //
 //   workgroup 0 ("critical"): for p = 0 .. nb-1: factor + invert the diagonal block in LDS (potrf_diag.h), publish
-//     L_pp and inv(L_pp); then the look-ahead that the next diagonal block waits for, without leaving the CU:
-//     L[p+1][p] = C(p+1, p) inv(L_pp)'  and  C(p+1, p+1) -= L[p+1][p] L[p+1][p]'.
+//     inv(L_pp) at once (every helper of the panel waits for it); then the look-ahead that the next diagonal block waits
+//     for, without leaving the CU: L[p+1][p] = C(p+1, p) inv(L_pp)'  and  C(p+1, p+1) -= L[p+1][p] L[p+1][p]' -- of the
+//     update only column block 0 before the next factorisation starts: the other sub-tiles, the store of L[p+1][p] and
+//     its flag are done by waves 1..3 inside that factorisation's first 16x16 step, where they would idle, and the two
+//     tiles of the panel after that are fetched into LDS by the same waves in its later steps (diag_core's hook).
 //   workgroups 1 .. H ("helpers"): pull tile jobs from one queue (an atomic counter over a list sorted by the panel at
 //     which a job can finish).  A job owns its tile in REGISTERS from C_0 to the end: it waits for the two L tiles of
 //     the next panel update (flags), applies it, and after the last one waits for inv(L_JJ) and publishes L_IJ.  Tiles
@@ -231,11 +234,11 @@ __device__ __forceinline__ void put_identity_corner(double *A) {
   A[(t >> 4) * DLD + 48 + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
 }
 
-// Fetching the next panel's two tiles while the factorisation still runs: at step kb = 2 of the factor routine wave 3
-// has nothing to do and waves 1 and 2 little, so wave 3 brings tile (p+1, p) into S1 and waves 1 / 2 one half each of
-// tile (p+1, p+1) into S2 -- if the helpers have already handed them over (one non-blocking look at the flag; they
-// usually have, a couple of microseconds into the factorisation).  What was not fetched here is fetched after the
-// factorisation the blocking way.
+// What waves 1..3 do inside the factor routine (diag_core's hook) while wave 0 is in its serial 16x16 steps.
+// Step 0: the rest of the look-ahead into THIS block (finish_lookahead).  Steps 2, 3 and the routine's tail: fetching the
+// NEXT panel's two tiles -- wave 3 brings tile (p+1, p) into S1 and waves 1 / 2 one half each of tile (p+1, p+1) into S2,
+// if the helpers have already handed them over (one non-blocking look at the flag per attempt; the hand-over usually
+// lands around step 3).  What was not fetched here is fetched after the factorisation the blocking way.
 struct Prefetch {
   const PArgs &a;
   const Flags &F;
@@ -433,7 +436,7 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       for (int jb = 0; jb < 4; ++jb) S1[(wave * 16 + lq + 4 * rr) * DLD + jb * 16 + lr] = lqv[jb][rr];
     __syncthreads();
     PST(p, 4);
-    PST(p, 5);
+    PST(p, 5);  // (slot kept for the stamp reader's layout)
     // The next factorisation's first step needs column block 0 of C(p+1, p+1) only (wave 0 factors sub-block (0, 0) and
     // solves the three below it in the same instruction stream): wave w applies the update to sub-tile (w, 0) now -- the
     // 64-deep chain from zero, then the subtraction (syrk_tile / NEAR update) -- and waves 1..3 do the other six lower
