@@ -272,7 +272,7 @@ def main():
     ctx.profile_enable(False)
 
     phases = {}
-    for ph in ("kxx", "potrf", "trtri", "alpha", "basis", "mean", "ksx", "post", "score", "argmax", "exchange"):
+    for ph in ("prep", "kxx", "potrf", "trtri", "alpha", "basis", "mean", "ksx", "post", "score", "argmax", "exchange"):
         ms, n = ctx.profile_get(ph)
         if n:
             phases[ph] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
@@ -292,7 +292,7 @@ def main():
     if ksx:
         ksx_gbs = rows_per_launch * (8.0 * Npad + 8.0 * d) / (ksx["ms_avg"] * 1e-3) / 1e9
     n_fits = max(1, args.steps * n_samples)
-    fit_ms = sum(phases[p]["ms_total"] for p in ("kxx", "potrf", "trtri", "alpha") if p in phases) / n_fits
+    fit_ms = sum(phases[p]["ms_total"] for p in ("prep", "kxx", "potrf", "trtri", "alpha") if p in phases) / n_fits
     traffic, traffic_src = pmc_traffic(rows_per_launch, N)
 
     line = {

@@ -21,7 +21,7 @@ SYMBOLS = [
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove", "b7_grid_remove_rows",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_predict_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
-    "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global",
+    "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global",
     "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
@@ -111,6 +111,7 @@ def load():
         "b7_score_ei": (i32, [vp, vp, dbl]),
         "b7_score_cb": (i32, [vp, dbl, i32, dbl]),
         "b7_score_finish": (i32, [vp, dbl, C.POINTER(dbl), C.POINTER(i64), vp]),
+        "b7_comm_pick_winner": (i32, [vp, i32, C.POINTER(dbl), C.POINTER(i64)]),
         "b7_comm_unique_id": (i32, [vp]),
         "b7_comm_init": (i32, [vp, i32, i32, vp]),
         "b7_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
@@ -564,6 +565,20 @@ def comm_unique_id():
     if rc != B7_OK:
         raise Bot7HipError(rc, (load().b7_last_error(None) or b"").decode())
     return buf.raw
+
+
+def comm_pick_winner(pairs):
+    """The library's winner rule on a list of (value, global_idx1) pairs (idx1 <= 0: empty shard).  Host-only."""
+    tab = np.zeros((len(pairs), 2), dtype=np.uint64)
+    for r, (v, i) in enumerate(pairs):
+        if int(i) > 0:
+            tab[r, 0] = np.array([v], dtype=np.float64).view(np.uint64)[0]
+            tab[r, 1] = int(i)
+    v, i = C.c_double(), C.c_int64()
+    rc = load().b7_comm_pick_winner(_ptr(tab), len(pairs), C.byref(v), C.byref(i))
+    if rc != B7_OK:
+        raise Bot7HipError(rc, "every shard is empty")
+    return v.value, i.value
 
 
 def sobol_direction_numbers(dims):

@@ -92,6 +92,16 @@ bool pick_winner(const uint64_t *tab, int world, double *val, int64_t *idx1) {
 
 extern "C" {
 
+int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int64_t *best_idx1) {
+  if (!table || world < 1) return B7_ERR_INVALID;
+  double v = 0.0;
+  int64_t i = 0;
+  if (!pick_winner(table, world, &v, &i)) return B7_ERR_STATE;  // every shard empty
+  if (best_val) *best_val = v;
+  if (best_idx1) *best_idx1 = i;
+  return B7_OK;
+}
+
 int b7_comm_unique_id(void *id_out) {
   if (!id_out) return B7_ERR_INVALID;
   Rccl &r = rccl();

@@ -325,6 +325,7 @@ int ksx_dispatch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t M
 }  // namespace
 
 int launch_prep_obs(b7_ctx *c, const double *xobs, const double *ls_dev, int N, int d) {
+  PhaseScope ps(c, "prep");
   const size_t lds = sizeof(double) * (64 * (size_t)(c->dpad + 1) + c->dpad);
   hipLaunchKernelGGL(prep_obs_kernel, dim3((c->Npad + 63) / 64), dim3(64), lds, c->stream, xobs, ls_dev,
                      (double *)c->w.p, (double *)c->zsc.p, (double *)c->zss.p, N, c->Npad, d, c->dpad);

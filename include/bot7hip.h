@@ -249,6 +249,11 @@ int b7_comm_destroy(b7_ctx *ctx); /* also done by b7_destroy */
 #define B7_COMM_MAX 1
 #define B7_COMM_MIN 2
 int b7_comm_allreduce_f64(b7_ctx *ctx, double *inout, int n, int op);
+/* Host-only, needs no context and no GPU: the rule every rank applies to the gathered [world, 2] table of 64-bit words
+ * (value bits, global 1-based index; index 0 = that rank's shard was empty) -- TH's max over the union of the shards:
+ * the first NaN wins, else the largest value, ties to the lowest global index.  B7_ERR_STATE when every shard is empty.
+ * Exposed so that the rule can be checked for any world size without that many GPUs. */
+int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int64_t *best_idx1);
 /* b7_score_finish across ranks: score:div(divisor) on this rank's shard, local first-maximum on the device, the
  * (value, global 1-based index = global_row_offset + local index) pairs of all ranks exchanged by one all-reduce,
  * and on every rank the same winner by TH's rule (first NaN, else max, ties to the lowest global index): exactly
@@ -272,7 +277,7 @@ int b7_timer_stop(b7_ctx *ctx, int slot);
 int b7_timer_ms(b7_ctx *ctx, int slot, float *ms_out);
 
 /* Per-kernel-phase event timing inside fit/predict/score (off by default: it serialises phases).
- * Phases: "kxx" "potrf" "trtri" "alpha" "ksx" "post" "score" "argmax" "exchange" "sobol" "remove".
+ * Phases: "prep" "kxx" "potrf" "trtri" "alpha" "ksx" "post" "score" "argmax" "exchange" "sobol" "remove".
  * b7_profile_get returns the summed milliseconds and launch count since the last reset. */
 int b7_profile_enable(b7_ctx *ctx, int on);
 int b7_profile_reset(b7_ctx *ctx);

@@ -57,6 +57,7 @@ int b7_comm_init(b7_ctx *ctx, int rank, int world, const void *id);
 int b7_comm_info(b7_ctx *ctx, int *rank, int *world);
 int b7_comm_destroy(b7_ctx *ctx);
 int b7_comm_allreduce_f64(b7_ctx *ctx, double *inout, int n, int op);
+int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int64_t *best_idx1);
 int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offset, double *best_val, int64_t *best_idx1);
 int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff, int64_t M, int c, double *out);
 int b7_cb_compute(b7_ctx *ctx, const double *mean, const double *var, double tradeoff, int upper, double sign, int64_t M, int c, double *out);

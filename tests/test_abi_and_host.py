@@ -185,3 +185,35 @@ def test_sobol_skip_zero_is_kept():
             cfg["skip"] = skip
         bot7_amd.grids.sobol(cfg, context=FakeCtx())()
         assert calls[-1] == want
+
+
+def test_library_winner_rule_matches_th_max_for_any_world_size(orc):
+    """csrc/comm.hip's pick_winner (what b7_score_finish_global applies to the all-reduced table) on tables of 1..64
+    ranks built from sharded score vectors: the same (value, index) as TH's max on the unsharded vector -- ties to the
+    lowest global index, the first NaN wins, -0.0 and NaN payloads intact, empty shards ignored.  Host-only."""
+    rng = np.random.default_rng(7)
+    for case in range(6):
+        s = rng.normal(size=5003)
+        if case >= 1:
+            s[[100, 700, 4000]] = s.max() + 1.0
+        if case >= 3:
+            s[[900, 300]] = np.nan
+        if case == 5:
+            s[:] = -0.0
+        wi, wv = orc.c.argmax_first(s)
+        for G in (1, 2, 3, 8, 64):
+            pairs = []
+            for r in range(G):
+                lo, hi = dist.shard_range(s.size, r, G)
+                if hi > lo:
+                    i, v = orc.c.argmax_first(s[lo:hi])
+                    pairs.append((v, lo + i))
+                else:
+                    pairs.append((0.0, 0))
+            v, i = _lib.comm_pick_winner(pairs)
+            assert i == wi and (v == wv or (v != v and wv != wv)), (case, G)
+            assert np.signbit(v) == np.signbit(wv) or v != v
+            assert dist.pick_winner(pairs)[1] == wi                 # the Python restatement used by the gloo rehearsal
+    assert _lib.comm_pick_winner([(1.0, 0), (0.5, 7), (9.0, 0)]) == (0.5, 7)
+    with pytest.raises(bot7_amd.Bot7HipError):
+        _lib.comm_pick_winner([(1.0, 0), (2.0, 0)])
