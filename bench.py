@@ -226,6 +226,11 @@ def main():
     def score_add():
         ctx.score_ei(fmin, 0.0) if score == "ei" else ctx.score_cb()
 
+    spec = {"score": "ei", "fmin": fmin, "tradeoff": 0.0} if score == "ei" else {"score": "cb"}
+
+    def hyper_samples(samples):               # distinct hypers per sample, as a sampler would hand over
+        return [dict(hyp, lenscale_sq=hyp["lenscale_sq"] * (1.0 + 0.05 * s_i)) for s_i in range(samples)]
+
     def step(samples):
         if obj_name == "dngo":
             ctx.blr_fit_x(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean)
@@ -233,16 +238,10 @@ def main():
             ctx.blr_predict(download=False)
             ctx.score_reset()
             score_add()
-            div = 1.0
-        else:
-            for s_i in range(samples):        # bots/bayesopt.lua:73-78: one fit + predict + score:add per hyper sample
-                scale = 1.0 + 0.05 * s_i      # distinct hypers per sample, as a sampler would hand over
-                ctx.gp_predict_hyp(hyp["lenscale_sq"] * scale, hyp["amp"], hyp["noise"], hyp["mean"])  # fit + predict
-                if s_i == 0:
-                    ctx.score_reset()
-                score_add()
-            div = float(samples)
-        return shard.nominate(div, device=None if rccl else "cpu")
+            return shard.nominate(1.0, device=None if rccl else "cpu")
+        # bots/bayesopt.lua:56-99: per hyper sample one fit + posterior + score:add, then score:div and score:max(1)
+        # across all ranks -- b7_eval_nominate, one library call
+        return shard.eval_nominate(hyper_samples(samples), spec, device=None if rccl else "cpu")
 
     def fence():
         ctx.sync()
@@ -270,6 +269,10 @@ def main():
     ctx.profile_reset()
     elapsed, best = timed(args.steps, args.samples)
     ctx.profile_enable(False)
+    # the same K steps once more without the per-phase HIP events: at the small configurations the event records
+    # themselves (two per phase, ~16 per step) are a third of the step; at the headline size they are 0.1 %
+    elapsed_plain, best_plain = timed(args.steps, args.samples)
+    assert best_plain == best, "the nomination changed between two identical passes"
 
     phases = {}
     for ph in ("prep", "kxx", "potrf", "trtri", "alpha", "basis", "mean", "ksx", "post", "score", "argmax", "exchange"):
@@ -303,6 +306,7 @@ def main():
         "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_without_phase_events": elapsed_plain / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %s d=%d, N=%d obs (strided pick from the pool, SURVEY 8d), %d %s candidates per "
@@ -330,6 +334,9 @@ def main():
         "ksx_hbm_gbs": ksx_gbs, "ksx_hbm_frac": (ksx_gbs / HBM_PEAK_GBS) if ksx_gbs else None,
         "phases": phases,
         "best": {"value": best[0], "index1": best[1]},
+        "step_api": "b7_blr_* + b7_score_* + b7_score_finish_global" if obj_name == "dngo" else
+                    ("b7_eval_nominate (one call, one host synchronisation per step)" if ctx.comm_info()[1] == world
+                     else "b7_gp_predict_hyp + b7_score_* per sample, gloo exchange"),
     }
 
     extras = not args.no_extras and obj_name != "dngo"

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libbot7hip.so")
+# BOT7HIP_LIB: the same override the LuaJIT binding honours (lua/bot7hip_ffi.lua); diagnostic builds use it (tools/)
+_SO = os.environ.get("BOT7HIP_LIB") or os.path.join(_HERE, "libbot7hip.so")
 
 B7_OK = 0
 ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7_ERR_STATE",
@@ -21,7 +22,7 @@ SYMBOLS = [
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove", "b7_grid_remove_rows",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_predict_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
-    "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global",
+    "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global", "b7_eval_nominate",
     "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
@@ -36,6 +37,14 @@ class Bot7HipError(RuntimeError):
 class Hyp(C.Structure):
     _fields_ = [("lenscale_sq", C.POINTER(C.c_double)), ("amp", C.c_double), ("noise", C.c_double),
                 ("mean", C.c_double)]
+
+
+class ScoreSpec(C.Structure):
+    _fields_ = [("kind", C.c_int), ("tradeoff", C.c_double), ("upper", C.c_int), ("sign", C.c_double),
+                ("fmin", C.POINTER(C.c_double))]
+
+
+SCORE_EI, SCORE_CB = 1, 2
 
 
 class Mlp(C.Structure):
@@ -118,6 +127,8 @@ def load():
         "b7_comm_destroy": (i32, [vp]),
         "b7_comm_allreduce_f64": (i32, [vp, vp, i32, i32]),
         "b7_score_finish_global": (i32, [vp, dbl, i64, C.POINTER(dbl), C.POINTER(i64)]),
+        "b7_eval_nominate": (i32, [vp, i32, C.POINTER(Hyp), C.POINTER(ScoreSpec), i64, C.POINTER(dbl), C.POINTER(i64),
+                                   vp, vp]),
         "b7_ei_compute": (i32, [vp, vp, vp, vp, dbl, i64, i32, vp]),
         "b7_cb_compute": (i32, [vp, vp, vp, dbl, i32, dbl, i64, i32, vp]),
         "b7_argmax": (i32, [vp, vp, i64, C.POINTER(dbl), C.POINTER(i64)]),
@@ -504,6 +515,43 @@ class Context(object):
         v, i = C.c_double(), C.c_int64()
         self._ck(self._L.b7_score_finish_global(self._h, float(divisor), int(global_row_offset), C.byref(v),
                                                 C.byref(i)))
+        return v.value, i.value
+
+    def eval_nominate(self, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0,
+                      global_row_offset=0, want_report=False):
+        """bayesopt:eval + nominate in one call: hyps is a sequence of (lenscale_sq, amp, noise, mean) or dicts
+        with those keys; score "ei" (needs fmin) or "cb".  Returns (value, 1-based global index[, report])."""
+        S = len(hyps)
+        arr = (Hyp * S)()
+        keep = []
+        for s, h in enumerate(hyps):
+            if isinstance(h, dict):
+                h = (h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
+            ls = _f64(h[0]).ravel()
+            if ls.size != getattr(self, "_data_d", -1):
+                raise Bot7HipError(-1, "lenscale_sq must have d entries (call gp_set_data first)")
+            keep.append(ls)
+            arr[s] = Hyp(ls.ctypes.data_as(C.POINTER(C.c_double)), float(h[1]), float(h[2]), float(h[3]))
+        if score == "ei":
+            if fmin is None:
+                raise Bot7HipError(-1, "EI needs fmin")
+            fm = _f64(fmin).ravel()
+            spec = ScoreSpec(SCORE_EI, 0.0 if tradeoff is None else float(tradeoff), 0, 0.0,
+                             fm.ctypes.data_as(C.POINTER(C.c_double)))
+        elif score == "cb":
+            fm = None
+            spec = ScoreSpec(SCORE_CB, 1.0 if tradeoff is None else float(tradeoff), int(bool(upper)), float(sign),
+                             None)
+        else:
+            raise Bot7HipError(-1, "score must be 'ei' or 'cb'")
+        jit = np.zeros(S, dtype=np.float64) if want_report else None
+        info = np.zeros(S, dtype=np.int32) if want_report else None
+        v, i = C.c_double(), C.c_int64()
+        self._ck(self._L.b7_eval_nominate(self._h, S, arr, C.byref(spec), int(global_row_offset), C.byref(v),
+                                          C.byref(i), _ptr(jit), _ptr(info)))
+        self.fit_token += 1
+        if want_report:
+            return v.value, i.value, {"jitter": jit, "info": info}
         return v.value, i.value
 
     def ei_compute(self, mean, var, fmin, tradeoff=0.0):

@@ -3,7 +3,9 @@
 eval (bots/bayesopt.lua:56-82) keeps the reference's arithmetic -- score = zeros(M); per hyper sample
 score:add(acq); score:div(nSamples) -- but the accumulator lives on the GPU (b7_score_reset / _ei|_cb /
 _finish) so no M-vector crosses PCIe per sample; nominate (:85-99) takes the arg-max from the same finish call
-(score:max(1): first maximum, 1-based)."""
+(score:max(1): first maximum, 1-based).  When only the winner is wanted (nominate) and the score has a device
+spec, the whole of eval + max is ONE library call, b7_eval_nominate: same hyper samples, same arithmetic, one host
+synchronisation instead of one per sample (config.bot.fused, default True)."""
 import numpy as np
 
 from .abstract import abstract
@@ -51,6 +53,14 @@ class bayesopt(abstract):
             return scores, val, idx
         model.sample_hypers(X_obs, Y_obs)                         # :68 (burn-in call)
         nSamples = self.config["bot"]["nSamples"]
+        spec = getattr(self.score, "device_spec", None)
+        if not want_scores and spec is not None and self.config["bot"].get("fused", True) \
+                and hasattr(model, "stage"):       # (the driver never hands pending points to the score, :66,76)
+            hyps = [model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True)) for _ in range(nSamples)]
+            model.stage(X_obs, Y_obs, X_hid)                      # data + grid resident (uploads only what changed)
+            val, idx = ctx.eval_nominate(hyps, **spec(Y_obs))     # :73-79 + :96 in one call
+            self.last_scores = None
+            return None, val, idx
         first = True
         for _ in range(nSamples):                                 # :73-78
             hyp = model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True))

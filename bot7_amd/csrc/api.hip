@@ -130,6 +130,7 @@ int b7_create(b7_ctx **out, int device_id) {
   c->cus = prop.multiProcessorCount;
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
+  if (const char *pv = getenv("B7_POST_SHAPE")) c->post_shape = atoi(pv) == 8 ? 8 : 4;  // A/B of the large-grid posterior kernel
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
@@ -180,6 +181,7 @@ void b7_destroy(b7_ctx *c) {
     }
   resolve_phases(c);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->pin_eval) (void)hipHostFree(c->pin_eval);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
   if (c->ev_fit) (void)hipEventDestroy(c->ev_fit);
@@ -412,6 +414,8 @@ int b7_gp_set_data(b7_ctx *c, const double *X, const double *Y, int N, int d, in
 }
 
 static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, double *var);
+static int check_hyp(b7_ctx *c, const b7_hyp *hyp, int d);
+static int fit_front(b7_ctx *c, const b7_hyp *hyp, const double *ls_dev);
 
 // then_predict: the posterior over the resident grid is enqueued right behind the fit, before the host has seen the
 // pivot report, and the host only waits for the report (an event), not for the prediction.  If the report says the
@@ -420,20 +424,9 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
                         bool then_predict) {
   if (!c) return B7_ERR_INVALID;
   if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "gp_fit_hyp: call b7_gp_set_data first");
-  if (!hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit_hyp: NULL argument");
   const int N = c->N, d = c->dfit, ycols = c->ycols;
-  for (int k = 0; k < d; ++k)
-    if (!(hyp->lenscale_sq[k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: lenscale_sq[%d] must be > 0", k);
-  if (!(hyp->amp > 0.0) || !(hyp->noise >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: amp > 0, noise >= 0");
+  B7_TRY(check_hyp(c, hyp, d));
   B7_HIP(c, hipSetDevice(c->device));
-
-  c->fitted = false;
-  c->model_kind = 0;
-  c->predicted = false;
-  c->amp = hyp->amp;
-  c->noise = hyp->noise;
-  c->mean = hyp->mean;
-  const size_t np = (size_t)c->Npad;
 
   // the only upload of a fit: d lengthscales, through the pinned staging slot [8192, 8960) (free again once the
   // synchronisation that ends every fit has passed); amp / noise / mean travel as kernel arguments
@@ -441,13 +434,7 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
   double *ls_dev = (double *)c->scratch.p;  // first 4096 bytes of scratch: up to 512 doubles
   memcpy(ls_stage, hyp->lenscale_sq, sizeof(double) * d);
   B7_HIP(c, hipMemcpyAsync(ls_dev, ls_stage, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
-  {
-    const int64_t ntotal = (int64_t)np * ycols;
-    hipLaunchKernelGGL(resid_kernel, dim3((unsigned)((ntotal + 255) / 256)), dim3(256), 0, c->stream,
-                       (const double *)c->ybuf.p, (double *)c->resid.p, (int64_t)N * ycols, ntotal, hyp->mean);
-  }
-  B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
-  B7_TRY(launch_kxx(c, hyp->noise));
+  B7_TRY(fit_front(c, hyp, ls_dev));
 
   // First attempt with everything that follows it enqueued BEFORE the host looks at the pivot report: when the
   // inverse came out of the factorisation itself, alpha and the likelihood terms do not need the host, and one
@@ -635,6 +622,148 @@ int b7_gp_predict_hyp(b7_ctx *c, const b7_hyp *hyp, double *mean_host, double *v
   if (var_host)
     B7_HIP(c, hipMemcpyAsync(var_host, c->var.p, sizeof(double) * (size_t)c->M, hipMemcpyDeviceToHost, c->stream));
   if (mean_host || var_host) B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
+}
+
+// ---- bayesopt:eval + nominate as one call ------------------------------------------------------------------
+// bots/bayesopt.lua:56-99: score = (1/S) sum_s acq(model, hyp_s, X_obs, Y_obs, X_hid), then score:max(1).  The
+// separate entry points (b7_gp_predict_hyp, b7_score_*, b7_score_finish*) cost one host round trip per hyper sample
+// (the pivot report) plus one for the arg-max; at small N and M (cfg2: 0.2 ms of GPU work per sample) the round trips
+// are a third of the wall time.  Here every sample's fit, posterior and score:add are enqueued back to back, each
+// fit's 16-byte pivot report is copied into its own pinned slot in stream order, the arg-max follows, and the host
+// synchronises ONCE.  A report that says "pivot failed" or "hand-off timed out" (rare) throws the accumulated score
+// away and redoes the whole nomination through the per-sample path, jitter schedule included, so the result is the
+// one the separate calls give.
+static int stage_fmin(b7_ctx *c, const double *fmin, double **fd_out) {
+  double *fh = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 4096);
+  double *fd = (double *)((char *)c->scratch.p + 2048);
+  if (!c->fmin_staged || memcmp(fh, fmin, sizeof(double) * c->ycols) != 0) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(fh, fmin, sizeof(double) * c->ycols);
+    c->fmin_staged = true;
+  }
+  B7_HIP(c, hipMemcpyAsync(fd, fh, sizeof(double) * c->ycols, hipMemcpyHostToDevice, c->stream));
+  *fd_out = fd;
+  return B7_OK;
+}
+
+static int score_add(b7_ctx *c, const b7_score_spec *sp, const double *fd) {
+  if (sp->kind == B7_SCORE_EI)
+    return launch_ei(c, (const double *)c->mu.p, (const double *)c->var.p, fd, sp->tradeoff, c->M, c->ycols,
+                     (double *)c->acc.p, true);
+  return launch_cb(c, (const double *)c->mu.p, (const double *)c->var.p, sp->tradeoff, sp->upper, sp->sign, c->M,
+                   c->ycols, (double *)c->acc.p, true);
+}
+
+static int check_hyp(b7_ctx *c, const b7_hyp *hyp, int d) {
+  if (!hyp || !hyp->lenscale_sq) return b7_fail(c, B7_ERR_INVALID, "gp_fit_hyp: NULL argument");
+  for (int k = 0; k < d; ++k)
+    if (!(hyp->lenscale_sq[k] > 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: lenscale_sq[%d] must be > 0", k);
+  if (!(hyp->amp > 0.0) || !(hyp->noise >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_fit: amp > 0, noise >= 0");
+  return B7_OK;
+}
+
+// residual, observation scaling and K(X,X) of one hyper sample whose lengthscales are (on their way) at ls_dev
+static int fit_front(b7_ctx *c, const b7_hyp *hyp, const double *ls_dev) {
+  const int N = c->N, d = c->dfit, ycols = c->ycols;
+  c->fitted = false;
+  c->model_kind = 0;
+  c->predicted = false;
+  c->amp = hyp->amp;
+  c->noise = hyp->noise;
+  c->mean = hyp->mean;
+  const int64_t ntotal = (int64_t)c->Npad * ycols;
+  hipLaunchKernelGGL(resid_kernel, dim3((unsigned)((ntotal + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double *)c->ybuf.p, (double *)c->resid.p, (int64_t)N * ycols, ntotal, hyp->mean);
+  B7_TRY(launch_prep_obs(c, (const double *)c->xobs.p, ls_dev, N, d));
+  return launch_kxx(c, hyp->noise);
+}
+
+int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset,
+                     double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (S < 1 || !hyps || !spec) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: S >= 1, hyps and spec required");
+  if (spec->kind != B7_SCORE_EI && spec->kind != B7_SCORE_CB)
+    return b7_fail(c, B7_ERR_INVALID, "eval_nominate: unknown score kind %d", spec->kind);
+  if (spec->kind == B7_SCORE_EI && !spec->fmin) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: EI needs fmin");
+  if (global_row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: negative row offset");
+  if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "eval_nominate: call b7_gp_set_data first");
+  if (c->M > 0 && c->d != c->dfit)
+    return b7_fail(c, B7_ERR_INVALID, "eval_nominate: grid dims %d != data dims %d", c->d, c->dfit);
+  const int d = c->dfit;
+  for (int s = 0; s < S; ++s) B7_TRY(check_hyp(c, &hyps[s], d));
+  B7_HIP(c, hipSetDevice(c->device));
+  if (jitter_out) std::fill(jitter_out, jitter_out + S, 0.0);
+  if (info_out) std::fill(info_out, info_out + S, 0);
+  const bool exchange = c->comm && c->comm_world > 1;
+  if (c->M == 0) {  // an empty shard: nothing to score, but the exchange is collective
+    if (!exchange) return b7_fail(c, B7_ERR_STATE, "eval_nominate: no candidate grid on this context");
+    return b7_score_finish_global(c, (double)S, global_row_offset, best_val, best_idx1);
+  }
+  B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M * c->ycols));
+  B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
+  B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
+  {  // predict_into's workspace, sized now: a reallocation inside the loop would synchronise
+    const size_t row_bytes = sizeof(double) * (size_t)c->Npad;
+    int64_t chunk = (int64_t)(c->ks_bytes / row_bytes) / B7_MROWS * B7_MROWS;
+    if (chunk < B7_MROWS) chunk = B7_MROWS;
+    const int64_t Mpad = round_up(c->M, B7_MROWS);
+    B7_TRY(b7_ensure(c, c->ks, (size_t)(chunk > Mpad ? Mpad : chunk) * row_bytes));
+  }
+  // lengthscales of all S samples: one pinned staging block, one upload
+  const size_t ls_bytes = sizeof(double) * (size_t)S * d, rep_bytes = 16 * (size_t)S;
+  if (c->pin_eval_bytes < ls_bytes + rep_bytes) {
+    if (c->pin_eval) (void)hipHostFree(c->pin_eval);
+    c->pin_eval = nullptr;
+    c->pin_eval_bytes = 0;
+    B7_HIP(c, hipHostMalloc(&c->pin_eval, 2 * (ls_bytes + rep_bytes), hipHostMallocDefault));
+    c->pin_eval_bytes = 2 * (ls_bytes + rep_bytes);
+  }
+  B7_TRY(b7_ensure(c, c->bhyp, ls_bytes));
+  int *reports = static_cast<int *>(c->pin_eval);                                        // [S][4]
+  double *ls_host = reinterpret_cast<double *>(static_cast<char *>(c->pin_eval) + rep_bytes);  // [S][d]
+  for (int s = 0; s < S; ++s) memcpy(ls_host + (size_t)s * d, hyps[s].lenscale_sq, sizeof(double) * d);
+  memset(reports, 0xff, rep_bytes);
+  B7_HIP(c, hipMemcpyAsync(c->bhyp.p, ls_host, ls_bytes, hipMemcpyHostToDevice, c->stream));
+  double *fd = nullptr;
+  if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
+
+  B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69
+  c->acc_valid = true;
+  bool speculative = true;
+  for (int s = 0; s < S && speculative; ++s) {
+    B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
+    B7_TRY(launch_potrf(c, 0.0, true));
+    if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
+    B7_TRY(launch_alpha(c));
+    B7_HIP(c, hipMemcpyAsync(reports + 4 * s, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
+    c->fitted = true;
+    B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
+    c->predicted = true;
+    c->Mpred = c->M;
+    B7_TRY(score_add(c, spec, fd));
+  }
+  // without a communicator the arg-max is enqueued before the host has seen any report; with one, the collective
+  // must come after the check (a rank that redoes its nomination would otherwise issue one collective too many)
+  if (!exchange) B7_TRY(b7_score_finish_global(c, (double)S, global_row_offset, best_val, best_idx1));
+  else B7_HIP(c, hipStreamSynchronize(c->stream));
+  bool clean = true;
+  for (int s = 0; s < S; ++s) clean = clean && reports[4 * s] == 0 && reports[4 * s + 1] == 0;
+  if (!clean) {
+    bool aborted = false;
+    for (int s = 0; s < S; ++s) aborted = aborted || reports[4 * s + 1] != 0;
+    if (aborted) persist_gave_up(c);
+    B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));
+    for (int s = 0; s < S; ++s) {
+      B7_TRY(fit_hyp_core(c, &hyps[s], nullptr, jitter_out ? jitter_out + s : nullptr, info_out ? info_out + s : nullptr,
+                          true));
+      c->predicted = true;
+      c->Mpred = c->M;
+      if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
+      B7_TRY(score_add(c, spec, fd));
+    }
+  }
+  if (!clean || exchange) B7_TRY(b7_score_finish_global(c, (double)S, global_row_offset, best_val, best_idx1));
   return B7_OK;
 }
 
@@ -1159,14 +1288,8 @@ int b7_score_ei(b7_ctx *c, const double *fmin, double tradeoff) {
   // outlive this call and the copy is a true asynchronous one.  The staging slot may still be the source of an
   // earlier copy in flight, hence the wait when the values change (once per nomination: fmin is the same for every
   // hyper sample of a marginalisation loop).
-  double *fh = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 4096);
-  double *fd = (double *)((char *)c->scratch.p + 2048);
-  if (!c->fmin_staged || memcmp(fh, fmin, sizeof(double) * c->ycols) != 0) {
-    B7_HIP(c, hipStreamSynchronize(c->stream));
-    memcpy(fh, fmin, sizeof(double) * c->ycols);
-    c->fmin_staged = true;
-  }
-  B7_HIP(c, hipMemcpyAsync(fd, fh, sizeof(double) * c->ycols, hipMemcpyHostToDevice, c->stream));
+  double *fd = nullptr;
+  B7_TRY(stage_fmin(c, fmin, &fd));
   return launch_ei(c, (const double *)c->mu.p, (const double *)c->var.p, fd, tradeoff, c->M, c->ycols,
                    (double *)c->acc.p, true);
 }

@@ -42,6 +42,7 @@ struct b7_ctx {
   hipEvent_t ev_fit = nullptr;  // behind the fit report's copy: b7_gp_predict_hyp waits for it, not for the prediction
   std::string err;
   int cus = 0;
+  int post_shape = 4;  // waves of the large-grid posterior kernel: 4 (one per SIMD, pipelined) or 8 (B7_POST_SHAPE=8)
 
   // ---- candidate grid (row-major M x d), ping-pong for stable row removal
   DevBuf grid[2];
@@ -90,6 +91,8 @@ struct b7_ctx {
   // staging: kernels write
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
+  void *pin_eval = nullptr;  // b7_eval_nominate: [S][4] pivot reports + [S][d] lengthscale staging (pinned)
+  size_t pin_eval_bytes = 0;
   void *pinned_dev = nullptr;
   bool fmin_staged = false;  // the fmin staging slot of the pinned block holds a caller's values
   bool potrf_attrs_set = false;  // dynamic-LDS limits of the Cholesky kernels raised (once per context)

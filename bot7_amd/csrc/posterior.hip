@@ -20,6 +20,17 @@
 // (t+1)/T-weighted ~ (T+1)/2 times from L2/MALL/HBM (T = Npad/128 n-tiles), Linv once per block from L2.
 #include "b7_internal.h"
 #include "gemm_f64.h"
+#include <utility>
+
+#ifdef B7_POST_STAMPS
+// Diagnostic build only (tools/post_clock.py; never defined for the shipped library): every workgroup records
+// s_memtime / s_memrealtime at its start and end into a buffer nothing else reads; the in-kernel clock is
+// d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long b7_post_stamps[4 * 4096];
+extern "C" int b7dbg_post_stamps(unsigned long long *out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(b7_post_stamps), sizeof(unsigned long long) * 4 * nblocks);
+}
+#endif
 
 namespace {
 
@@ -34,6 +45,10 @@ __global__ void __launch_bounds__(64 * WM * WN, MINW)
   extern __shared__ __align__(16) double sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double *B = ks + (int64_t)blockIdx.x * BN * Npad;  // this block's BN candidate rows of K*
+#ifdef B7_POST_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   double colss[GP::TN] = {};
   // PRIO: with two waves per SIMD the second-dispatched half of the workgroup loses issue arbitration to the older
   // half at the start of every stage; one static priority raise for that half evens it out (the condition must be
@@ -50,7 +65,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MINW)
 #pragma unroll
       for (int i = 0; i < GP::TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+        for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[i][j][r], acc[i][j][r], s);  // explicit: the order is part of the result
       colss[j] += s;
     }
   }
@@ -77,6 +92,295 @@ __global__ void __launch_bounds__(64 * WM * WN, MINW)
       var[g] = v;
     }
   }
+#ifdef B7_POST_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    unsigned long long *o = b7_post_stamps + 4 * blockIdx.x;
+    o[0] = st0, o[1] = sr0, o[2] = st1, o[3] = sr1;
+  }
+#endif
+}
+
+// ---- the large-grid shape: one wave per SIMD, one continuous MFMA stream ----------------------------------------------
+// Same block tile (128 rows of L^-1 x 256 candidates), same LDS image (16-deep stages, odd row stride), same
+// arithmetic bit for bit -- but FOUR waves of 128 x 64 instead of eight of 64 x 64.  In-kernel stamps of the 8-wave kernel
+// (tools/post_clock.py: s_memtime / s_memrealtime around every workgroup, >= 2 s of back-to-back launches) showed the
+// chip holding 2.37 GHz, not the 2.1 GHz round 1 inferred from counters, and the workgroup spending 14 % of its
+// cycles NOT issuing MFMAs: the two waves of a SIMD run in lock step, so both sit in the same LDS wait at mid-stage
+// and at the barrier, and 256 registers per wave leave no room to fetch fragments ahead.  With 512 registers a wave
+// keeps two fragment sets and the next stage's global data in flight:
+//   first half of stage n  : MFMAs of k-steps 0,1 (set F0) | read F1 = k-steps 2,3 of stage n | store G (stage n+1,
+//                            loaded a stage ago) into the other LDS buffer | issue the global loads of stage n+2
+//   barrier (mid-stage)    : stage n+1's image is complete; nobody reads this stage's buffer any more
+//   second half of stage n : MFMAs of k-steps 2,3 (set F1) | read F0 = k-steps 0,1 of stage n+1
+// The stage stream runs across the n-tiles without a prologue per tile; in the 8 diagonal stages of a tile the 16-row
+// strips above the diagonal are skipped exactly as before.  Two LDS buffers suffice: every read of a buffer precedes the
+// mid-stage barrier of the stage after the one that computes from it, every write to it follows that barrier.
+namespace w4 {
+constexpr int BM = 128, BN = 256, BK = 16, LD = BK + 1;
+constexpr int A_DBL = BM * LD, STAGE_DBL = (BM + BN) * LD;
+constexpr int LDS_BYTES = 2 * STAGE_DBL * 8;
+
+// The 32 accumulator tiles of a wave (8 strips of 16 rows x 4 strips of 16 candidates, 8 registers each) are the 256
+// AGPRs a0..a255, addressed by NUMBER inside inline asm and never held in a C++ variable: tile (i, j) is
+// a[8 (4 i + j) : 8 (4 i + j) + 7].  (As compiler-visible values -- the builtin, or "+a" asm operands -- the register
+// allocator carried some of them across the loop back-edge in VGPRs: hundreds of v_accvgpr copies per stage, spills, and
+// no hazard handling after an asm MFMA.)  Every asm statement below names all 256 as clobbered, so the compiler keeps
+// nothing of its own in them; tests/test_abi_and_host.py checks in the generated ISA that no instruction outside these
+// asm statements touches an AGPR.
+#define B7_W4_ACC_REGS \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+  "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", \
+  "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", \
+  "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", \
+  "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", \
+  "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", \
+  "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", \
+  "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", \
+  "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", \
+  "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+  "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", \
+  "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", \
+  "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", \
+  "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", \
+  "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", \
+  "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", \
+  "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", \
+  "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", \
+  "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
+template <int I, int J, bool ZERO>
+__device__ __forceinline__ void mfma_tile(double a, double b) {
+  constexpr int lo = 8 * (4 * I + J);
+  if constexpr (ZERO)
+    asm volatile("v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, 0" ::"v"(a), "v"(b), "n"(lo), "n"(lo + 7) : B7_W4_ACC_REGS);
+  else
+    asm volatile("v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(lo), "n"(lo + 7)
+                 : B7_W4_ACC_REGS);
+}
+
+// sum of squares of accumulator tile (I, J): the caller has drained the matrix pipe (s_nop) before the first one
+template <int I, int J>
+__device__ __forceinline__ void read_tile(double (&v)[4]) {
+  constexpr int lo = 8 * (4 * I + J);
+  unsigned w[8];
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\tv_accvgpr_read_b32 %2, a[%10]\n\t"
+      "v_accvgpr_read_b32 %3, a[%11]\n\tv_accvgpr_read_b32 %4, a[%12]\n\tv_accvgpr_read_b32 %5, a[%13]\n\t"
+      "v_accvgpr_read_b32 %6, a[%14]\n\tv_accvgpr_read_b32 %7, a[%15]"
+      : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])
+      : "n"(lo), "n"(lo + 1), "n"(lo + 2), "n"(lo + 3), "n"(lo + 4), "n"(lo + 5), "n"(lo + 6), "n"(lo + 7));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = __hiloint2double((int)w[2 * r + 1], (int)w[2 * r]);
+}
+
+struct Frags {
+  double a[2][8], b[2][4];  // two k-steps: 8 strips of L^-1 rows, 4 strips of candidates
+};
+struct Stage {  // global data of one stage in flight: 4 + 8 sixteen-byte chunks per thread
+  d2_t c[12];
+};
+struct Cursor {  // (n-tile, 16-deep k block) of a stage; clamps at the last stage
+  int t, kb, ntiles;
+  __device__ __forceinline__ void advance() {
+    if (kb + 1 < (t + 1) * (BM / BK)) {
+      ++kb;
+    } else if (t + 1 < ntiles) {
+      ++t;
+      kb = 0;
+    }
+  }
+};
+
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// fragment pair P of a two-k-step set: P < 4 candidates strip P, else rows strip P - 4 (k-steps s0, s0 + 1)
+template <int P, int S0>
+__device__ __forceinline__ void read_pair(Frags &f, const double *__restrict__ sa, const double *__restrict__ sb) {
+  if constexpr (P < 4) {
+    f.b[0][P] = sb[P * 16 * LD + 4 * S0];
+    f.b[1][P] = sb[P * 16 * LD + 4 * S0 + 4];
+  } else {
+    f.a[0][P - 4] = sa[(P - 4) * 16 * LD + 4 * S0];
+    f.a[1][P - 4] = sa[(P - 4) * 16 * LD + 4 * S0 + 4];
+  }
+}
+
+// chunk C of a stage: C < 4 rows r0 + 32 C of the L^-1 tile, else candidates r0 + 32 (C - 4) of the K* tile
+template <int C>
+__device__ __forceinline__ void load_chunk(Stage &g, const double *__restrict__ qa, const double *__restrict__ qb,
+                                           int64_t lda) {
+  if constexpr (C < 4)
+    g.c[C] = *reinterpret_cast<const d2_t *>(qa + (int64_t)(32 * C) * lda);
+  else
+    g.c[C] = *reinterpret_cast<const d2_t *>(qb + (int64_t)(32 * (C - 4)) * lda);
+}
+template <int C>
+__device__ __forceinline__ void store_chunk(const Stage &g, double *__restrict__ w) {
+  constexpr int o = C < 4 ? 32 * C * LD : A_DBL + 32 * (C - 4) * LD;
+  w[o] = g.c[C][0];
+  w[o + 1] = g.c[C][1];
+}
+
+// One stage of the stream.  FIRST = first 16-row strip with anything to do (0 away from the diagonal block); ZERO: the
+// first stage of an n-tile starts the accumulators from zero.  NM MFMAs per half; the side operations of a half (first:
+// 12 fragment pairs of F1, 12 LDS stores of the next stage, 12 global loads of the one after; second: 12 fragment pairs
+// of the next stage's F0) are spread evenly between them, one every second MFMA away from the diagonal.
+template <int FIRST, bool ZERO>
+__device__ __forceinline__ void stage(Frags &f0, Frags &f1, Stage &g, double *__restrict__ cur, double *__restrict__ nxt,
+                                      int fa, int fb, int wofs, const double *__restrict__ pa,
+                                      const double *__restrict__ pb, int64_t lda, Cursor &ld) {
+  constexpr int NI = 8 - FIRST, NM = 2 * 4 * NI;
+  const double *qa = pa + ((int64_t)ld.t * BM) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
+  ld.advance();
+  // ---- first half: k-steps 0, 1 from F0
+  static_for<NM>([&](auto m_) {
+    constexpr int m = decltype(m_)::value, ks = m / (4 * NI), i = FIRST + (m % (4 * NI)) / 4, j = m % 4;
+    mfma_tile<i, j, ZERO && ks == 0>(f0.a[ks][i], f0.b[ks][j]);
+    static_for<36>([&](auto s_) {
+      constexpr int sidx = decltype(s_)::value;
+      if constexpr (sidx >= m * 36 / NM && sidx < (m + 1) * 36 / NM) {
+        if constexpr (sidx < 12) {
+          if constexpr (sidx < 4 || sidx - 4 >= FIRST) read_pair<sidx, 2>(f1, cur + fa, cur + fb);
+        } else if constexpr (sidx < 24) {
+          store_chunk<sidx - 12>(g, nxt + wofs);
+        } else {
+          load_chunk<sidx - 24>(g, qa, qb, lda);
+        }
+      }
+    });
+  });
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's part of the next image is in LDS (the loads stay in flight)
+  __builtin_amdgcn_s_barrier();
+  // ---- second half: k-steps 2, 3 from F1; the next stage's F0 (all strips: its FIRST is not known here)
+  static_for<NM>([&](auto m_) {
+    constexpr int m = decltype(m_)::value, ks = m / (4 * NI), i = FIRST + (m % (4 * NI)) / 4, j = m % 4;
+    mfma_tile<i, j, false>(f1.a[ks][i], f1.b[ks][j]);
+    static_for<12>([&](auto s_) {
+      constexpr int sidx = decltype(s_)::value;
+      if constexpr (sidx >= m * 12 / NM && sidx < (m + 1) * 12 / NM) read_pair<sidx, 0>(f0, nxt + fa, nxt + fb);
+    });
+  });
+}
+
+__global__ void __launch_bounds__(256)
+    post_kernel_w4(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0, int64_t Mtotal,
+                   double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var) {
+  extern __shared__ __align__(16) double sm[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef B7_POST_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+  const int64_t lda = Npad;
+  // staging: thread -> (row r0 + 32 i, 16-byte chunk kc) of both operand tiles
+  const int r0 = threadIdx.x >> 3, kc = threadIdx.x & 7;
+  const double *pa = Linv + (int64_t)r0 * lda + 2 * kc;
+  const double *pb = ks + ((int64_t)blockIdx.x * BN + r0) * lda + 2 * kc;
+  const int wofs = r0 * LD + 2 * kc;
+  // fragments: lane -> (row or candidate lane & 15 of a strip, k = 4 s + (lane >> 4))
+  const int fa = (lane & 15) * LD + (lane >> 4);
+  const int fb = A_DBL + (wave * 64 + (lane & 15)) * LD + (lane >> 4);
+
+  const int ntiles = Npad / BM;
+  Cursor ld{0, 0, ntiles};
+  Stage g;
+  Frags f0, f1;
+  double *const b0 = sm, *const b1 = sm + STAGE_DBL;  // every tile has an even number of stages: it starts on b0
+  static_for<12>([&](auto c_) { load_chunk<decltype(c_)::value>(g, pa, pb, lda); });  // stage 0
+  ld.advance();
+  static_for<12>([&](auto c_) { store_chunk<decltype(c_)::value>(g, b0 + wofs); });
+  {
+    const double *qa = pa + ((int64_t)ld.t * BM) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
+    static_for<12>([&](auto c_) { load_chunk<decltype(c_)::value>(g, qa, qb, lda); });  // stage 1: stored during stage 0
+    ld.advance();
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  static_for<12>([&](auto p_) { read_pair<decltype(p_)::value, 0>(f0, b0 + fa, b0 + fb); });
+
+  double colss[2][4] = {};  // rows 0..63 and 64..127 of every n-tile apart: the summation order of the 8-wave shapes
+#define B7_STAGE(F, Z, CUR, NXT) stage<F, Z>(f0, f1, g, CUR, NXT, fa, fb, wofs, pa, pb, lda, ld)
+  for (int t = 0; t < ntiles; ++t) {
+    // 8 t stages away from the diagonal block, then its 8 stages (in stage q the strips 0..q-1 hold zeros only); the
+    // tile's first stage zeroes the accumulators; buffers alternate, b0 first
+    B7_STAGE(0, true, b0, b1);
+    if (t > 0) {
+      for (int p = 0; p < 4 * t - 1; ++p) {
+        B7_STAGE(0, false, b1, b0);
+        B7_STAGE(0, false, b0, b1);
+      }
+      B7_STAGE(0, false, b1, b0);
+      B7_STAGE(0, false, b0, b1);
+    }
+    B7_STAGE(1, false, b1, b0);
+    B7_STAGE(2, false, b0, b1);
+    B7_STAGE(3, false, b1, b0);
+    B7_STAGE(4, false, b0, b1);
+    B7_STAGE(5, false, b1, b0);
+    B7_STAGE(6, false, b0, b1);
+    B7_STAGE(7, false, b1, b0);
+    // the asm MFMAs are opaque to the compiler's hazard recogniser: drain the matrix pipe before VALU reads the tile
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    static_for<8>([&](auto hj_) {
+      constexpr int h = decltype(hj_)::value / 4, j = decltype(hj_)::value % 4;
+      double s = 0.0;
+      static_for<4>([&](auto i_) {
+        double v[4];
+        read_tile<4 * h + decltype(i_)::value, j>(v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = __builtin_fma(v[r], v[r], s);
+      });
+      colss[h][j] += s;
+    });
+  }
+#undef B7_STAGE
+
+  // lanes l, l^16, l^32, l^48 hold partial sums of the same candidate; then the two row halves
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double v0 = colss[0][j], v1 = colss[1][j];
+    v0 += __shfl_xor(v0, 16);
+    v0 += __shfl_xor(v0, 32);
+    v1 += __shfl_xor(v1, 16);
+    v1 += __shfl_xor(v1, 32);
+    const int64_t gidx = row0 + (int64_t)blockIdx.x * BN + wave * 64 + j * 16 + lane;
+    if (lane < 16 && gidx < Mtotal) {
+      double ss = v0;
+      ss += v1;
+      double v = (base + sgn * ss) + var_add;
+      if (clamp) v = (v < var_min) ? var_min : v;
+      var[gidx] = v;
+    }
+  }
+#ifdef B7_POST_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    unsigned long long *o = b7_post_stamps + 4 * blockIdx.x;
+    o[0] = st0, o[1] = sr0, o[2] = st1, o[3] = sr1;
+  }
+#endif
+}
+}  // namespace w4
+
+static int launch_post_w4(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(w4::post_kernel_w4),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES));
+  const bool blr = c->model_kind == 1;
+  hipLaunchKernelGGL(w4::post_kernel_w4, dim3((unsigned)(rows / w4::BN)), dim3(256), w4::LDS_BYTES, c->stream,
+                     (const double *)c->Linv.p, ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
+                     blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI, bool PRIO = false>
@@ -103,5 +407,6 @@ int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t
   // with fewer 256-candidate workgroups than CUs the 128-wide tile fills the chip (N = 2048, M = 32768: 2.6 vs 4.2 ms;
   // N = 256: 63 vs 83 us; a 64-wide one was slower again, 4.1 ms)
   if (rows / 256 < c->cus) return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);
-  return launch_post_variant<128, 256, 2, 4, 2, 1, true, true>(c, ks, row0, rows, Mtotal, var);
+  if (c->post_shape == 8) return launch_post_variant<128, 256, 2, 4, 2, 1, true, true>(c, ks, row0, rows, Mtotal, var);
+  return launch_post_w4(c, ks, row0, rows, Mtotal, var);
 }

@@ -79,6 +79,24 @@ class ShardedScorer(object):
     def make_random(self, dims, seed=0, mins=None, maxes=None, download=False):
         return self.ctx.grid_random(self.hi - self.lo, dims, seed, self.lo, mins, maxes, download=download)
 
+    def eval_nominate(self, hyps, spec, device=None, group=None):
+        """bayesopt:eval + nominate over the sharded grid (bots/bayesopt.lua:56-99): S fits + posteriors + score:adds
+        and the global arg-max.  spec: the keyword arguments of Context.eval_nominate (score, fmin, tradeoff, ...).
+        With a communicator on the context (or a world of one) this is ONE C-ABI call, b7_eval_nominate; the gloo
+        rehearsal runs the separate entry points and exchanges through torch.distributed."""
+        if self.ctx.comm_info()[1] == self.world:
+            return self.ctx.eval_nominate(hyps, global_row_offset=self.lo, **spec)
+        if self.hi > self.lo:
+            for s, h in enumerate(hyps):
+                self.ctx.gp_predict_hyp(h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
+                if s == 0:
+                    self.ctx.score_reset()
+                if spec["score"] == "ei":
+                    self.ctx.score_ei(spec["fmin"], spec.get("tradeoff") or 0.0)
+                else:
+                    self.ctx.score_cb(spec.get("tradeoff", 1.0), spec.get("upper", False), spec.get("sign", -1.0))
+        return self.nominate(float(len(hyps)), device=device, group=group)
+
     def nominate(self, divisor=1.0, device=None, group=None):
         """score:div + global score:max(1).  Returns (value, global 1-based index).
 

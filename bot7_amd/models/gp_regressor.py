@@ -269,6 +269,18 @@ class gp_regressor(abstract):
         return isinstance(X1, DeviceGrid) and X1.ctx is self.ctx and X1.shape[0] == self.ctx.grid_shape()[0] \
             and getattr(X1, "version", -1) == self.ctx.grid_version
 
+    def stage(self, X_obs, Y_obs, X_hid):
+        """Make (X_obs, Y_obs) the resident data and X_hid the resident grid of the context, uploading only what
+        is not there already (for b7_eval_nominate, which refits the resident data under S hyper samples)."""
+        X = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
+        Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
+        key = (X.shape, Y.shape, float(X.sum()), float(Y.sum()))
+        if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
+            self.ctx.gp_set_data(X, Y)
+            self._resident_key = (key, self.ctx.fit_token)
+        if not self._is_resident(X_hid):
+            self.ctx.grid_upload(np.atleast_2d(np.asarray(X_hid, dtype=np.float64)))
+
     def predict_device(self, X_obs, Y_obs, X_hid, hyp=None):
         """fit + predict leaving mean/var on the device (for the fused score path).  Uploads X_hid only when it
         is not the grid already resident on this context."""

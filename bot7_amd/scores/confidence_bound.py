@@ -29,6 +29,15 @@ class confidence_bound(abstract):
             raise ValueError("bound must be 'lower' or 'upper'")
         ctx.score_cb(_d(config.get("tradeoff"), 1.0), bound == "upper", _d(config.get("sign"), -1.0))
 
+    def device_spec(self, Y_obs=None, config=None):
+        """Keyword arguments of Context.eval_nominate for this score (b7_score_spec)."""
+        config = config or self.config
+        bound = str(_d(config.get("bound"), "lower")).lower()      # :72
+        if bound not in ("lower", "upper"):
+            raise ValueError("bound must be 'lower' or 'upper'")
+        return {"score": "cb", "tradeoff": _d(config.get("tradeoff"), 1.0), "upper": bound == "upper",
+                "sign": _d(config.get("sign"), -1.0)}
+
     def eval(self, model, hyp, X_obs, Y_obs, X_hid, X_pend=None, config=None):
         config = config or self.config
         model.predict_device(X_obs, Y_obs, X_hid, hyp)  # :63

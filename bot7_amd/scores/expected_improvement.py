@@ -23,6 +23,12 @@ class expected_improvement(abstract):
         fmin = np.asarray(Y_obs, dtype=np.float64).reshape(len(Y_obs), -1).min(axis=0)  # Y_obs:min(1), :64
         ctx.score_ei(fmin, config.get("tradeoff") or 0.0)
 
+    def device_spec(self, Y_obs, config=None):
+        """Keyword arguments of Context.eval_nominate for this score (b7_score_spec)."""
+        config = config or self.config
+        fmin = np.asarray(Y_obs, dtype=np.float64).reshape(len(Y_obs), -1).min(axis=0)  # Y_obs:min(1), :64
+        return {"score": "ei", "fmin": fmin, "tradeoff": config.get("tradeoff") or 0.0}
+
     def eval(self, model, hyp, X_obs, Y_obs, X_hid, X_pend=None, config=None):
         """EI.eval (:43-67): posterior at X_hid, fmins, EI.compute.  Returns the M scores on the host."""
         config = config or self.config

@@ -261,6 +261,27 @@ int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int6
 int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offset, double *best_val,
                            int64_t *best_idx1);
 
+/* ---- bayesopt:eval + nominate as ONE call (bots/bayesopt.lua:56-99) --------------------------- *
+ * score = (1/S) sum_s acq(model, hyp_s, X_obs, Y_obs, X_hid) over the resident data (b7_gp_set_data) and the
+ * resident grid, then score:max(1) -- across ranks when the context has a communicator, exactly as
+ * b7_score_finish_global.  Same results as the loop  { b7_gp_predict_hyp(hyp_s); b7_score_ei|cb } x S  +
+ * b7_score_finish_global(S, offset), bit for bit, but all S fits, posteriors and score:adds are enqueued back to
+ * back and the host synchronises once: each fit's pivot report is checked afterwards, and a failed pivot (or a
+ * hand-off time-out) redoes the nomination through the per-sample path with utils/math.lua:159-218's jitter
+ * schedule.  jitter_out / info_out: nullable, S entries (as b7_gp_fit's).  The accumulator holds score / S
+ * afterwards (b7_score_finish with divisor 1 downloads it). */
+#define B7_SCORE_EI 1 /* scores/expected_improvement.lua: needs fmin[ycols]; tradeoff = xi */
+#define B7_SCORE_CB 2 /* scores/confidence_bound.lua: tradeoff = kappa, upper, sign as b7_score_cb */
+typedef struct {
+  int kind;
+  double tradeoff;
+  int upper;
+  double sign;
+  const double *fmin;
+} b7_score_spec;
+int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset,
+                     double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
+
 /* EI.compute / conf_bound.compute / max on caller-provided host vectors (M x c mean, M var). */
 int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff,
                   int64_t M, int c, double *out);

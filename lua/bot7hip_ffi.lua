@@ -10,7 +10,7 @@ tests/test_lua_shims.py fails when the two differ, and checks every hip.C.b7_* c
 local ffi = require('ffi')
 
 ffi.cdef[[
--- BEGIN generated from include/bot7hip.h (tools/gen_lua_cdef.py)
+/* BEGIN generated from include/bot7hip.h (tools/gen_lua_cdef.py) */
 typedef struct b7_ctx b7_ctx;
 int b7_abi_version(void);
 int b7_create(b7_ctx **out, int device_id);
@@ -59,6 +59,8 @@ int b7_comm_destroy(b7_ctx *ctx);
 int b7_comm_allreduce_f64(b7_ctx *ctx, double *inout, int n, int op);
 int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int64_t *best_idx1);
 int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offset, double *best_val, int64_t *best_idx1);
+typedef struct { int kind; double tradeoff; int upper; double sign; const double *fmin; } b7_score_spec;
+int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset, double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
 int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff, int64_t M, int c, double *out);
 int b7_cb_compute(b7_ctx *ctx, const double *mean, const double *var, double tradeoff, int upper, double sign, int64_t M, int c, double *out);
 int b7_argmax(b7_ctx *ctx, const double *scores, int64_t M, double *best_val, int64_t *best_idx1);
@@ -68,7 +70,7 @@ int b7_timer_ms(b7_ctx *ctx, int slot, float *ms_out);
 int b7_profile_enable(b7_ctx *ctx, int on);
 int b7_profile_reset(b7_ctx *ctx);
 int b7_profile_get(b7_ctx *ctx, const char *phase, double *ms_total, int64_t *launches);
--- END generated
+/* END generated */
 ]]
 
 local C = ffi.load(os.getenv('BOT7HIP_LIB') or 'bot7hip')
@@ -89,6 +91,8 @@ M.COMM_ID_BYTES = 128
 M.COMM_SUM = 0
 M.COMM_MAX = 1
 M.COMM_MIN = 2
+M.SCORE_EI = 1
+M.SCORE_CB = 2
 M.MAX_TIMERS = 16
 -- END generated constants
 

@@ -71,15 +71,27 @@ local function same_data(self, X, Y)
          and k.c == Y:size(2) and k.xs == X:sum() and k.ys == Y:sum()   -- an allocator may hand the address out again
 end
 
-function model:fit(X_obs, Y_obs, hyp, want_nll)
-  local hyp = hyp or self.hyp
+-- (X_obs, Y_obs) resident on the device; uploads only when they are not the pair already there.  Returns Y as N x c.
+function model:stage_data(X_obs, Y_obs)
   local X = hip.pin(X_obs)
   local Y = hip.pin(Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs)
   if not (same_data(self, X, Y) and X_obs:isContiguous() and Y_obs:isContiguous()) then
-    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))
+    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))   -- synchronous
     self._data = {xp = torch.data(X), yp = torch.data(Y), n = X:size(1), d = X:size(2), c = Y:size(2),
                   xs = X:sum(), ys = Y:sum()}
   end
+  return Y
+end
+
+-- data and candidate grid resident (for b7_eval_nominate, lua/bots_bayesopt_hip.lua)
+function model:stage(X_obs, Y_obs, X_hid)
+  self:stage_data(X_obs, Y_obs)
+  if not hip.is_resident(X_hid) then hip.upload_grid(X_hid) end
+end
+
+function model:fit(X_obs, Y_obs, hyp, want_nll)
+  local hyp = hyp or self.hyp
+  local Y = self:stage_data(X_obs, Y_obs)
   local ls = hip.pin(hyp.lenscale_sq)
   local h  = ffi.new('b7_hyp', {hip.data(ls), hyp.amp, hyp.noise, hyp.mean})
   local nll, jit, info = ffi.new('double[?]', Y:size(2)), ffi.new('double[1]'), ffi.new('int[1]')
@@ -98,13 +110,7 @@ function model:nll(X_obs, Y_obs, hyp) return self:fit(X_obs, Y_obs, hyp or self.
 -- B likelihoods at once (thetas: B x (d+3) rows in the hyper-vector layout above): one persistent launch for all of them,
 -- the current fit stays as it is.  For multi-chain samplers and speculative step-out probes.
 function model:nll_batch(X_obs, Y_obs, thetas)
-  local X = hip.pin(X_obs)
-  local Y = hip.pin(Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs)
-  if not (same_data(self, X, Y) and X_obs:isContiguous() and Y_obs:isContiguous()) then
-    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))
-    self._data = {xp = torch.data(X), yp = torch.data(Y), n = X:size(1), d = X:size(2), c = Y:size(2),
-                  xs = X:sum(), ys = Y:sum()}
-  end
+  local Y = self:stage_data(X_obs, Y_obs)
   local B, d = thetas:size(1), thetas:size(2) - 3
   local ls   = thetas:narrow(2, 1, d):contiguous()
   local amp, noise, mean = thetas:select(2, d + 1):contiguous(), thetas:select(2, d + 2):contiguous(), thetas:select(2, d + 3):contiguous()
@@ -226,13 +232,7 @@ end
 function model:predict_device(X_obs, Y_obs, X_hid, hyp)
   local hyp = hyp or self.hyp
   if not hip.is_resident(X_hid) then hip.upload_grid(X_hid) end
-  local X = hip.pin(X_obs)
-  local Y = hip.pin(Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs)
-  if not (same_data(self, X, Y) and X_obs:isContiguous() and Y_obs:isContiguous()) then
-    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))
-    self._data = {xp = torch.data(X), yp = torch.data(Y), n = X:size(1), d = X:size(2), c = Y:size(2),
-                  xs = X:sum(), ys = Y:sum()}
-  end
+  local Y = self:stage_data(X_obs, Y_obs)
   local ls = hip.pin(hyp.lenscale_sq)
   local h  = ffi.new('b7_hyp', {hip.data(ls), hyp.amp, hyp.noise, hyp.mean})
   local jit, info = ffi.new('double[1]'), ffi.new('int[1]')

@@ -378,6 +378,135 @@ def test_marginalised_argmax_matches_oracle(ctx, orc, kind, d, N, M, obj, S):
     assert val == scores[idx - 1]
 
 
+@pytest.mark.parametrize("N,d,M", [(700, 6, 70000), (100, 3, 66000), (2048, 32, 65536 + 256)])
+def test_posterior_kernel_shapes_are_bit_identical(orc, monkeypatch, N, d, M):
+    """The large-grid posterior kernel (four waves of 128 x 64, accumulators in numbered AGPRs, one continuous MFMA
+    stream) against the eight-wave shape it replaced (B7_POST_SHAPE=8) and against the small-grid shape: same
+    variance bits for every candidate, and the oracle's values on a sample."""
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(None, orc, d, N, M, lambda X: np.sin(3.0 * X).sum(axis=1, keepdims=True))
+    out = []
+    for shape in ("4", "8"):
+        monkeypatch.setenv("B7_POST_SHAPE", shape)
+        c = bot7_amd.Context(0)
+        monkeypatch.delenv("B7_POST_SHAPE")
+        try:
+            c.grid_upload(X_hid)
+            c.gp_fit(X_obs, Y, **hyp)
+            out.append(c.gp_predict())
+            if shape == "4":                      # the small-grid shape: the same rows in a grid below one block per CU
+                c.grid_upload(X_hid[:4096])
+                small = c.gp_predict()
+        finally:
+            c.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][1][:4096], small[1])
+    f = orc.gp.fit(X_obs, Y, **hyp)
+    idx = np.linspace(0, M - 1, 300).astype(int)
+    mu_o, var_o = orc.gp.predict(f, X_hid[idx])
+    assert relerr(out[0][1][idx], var_o) < REL
+
+
+def _marg_hyps(hyp, S):
+    hyps = []
+    for s in range(S):
+        h = dict(hyp)
+        h["lenscale_sq"] = hyp["lenscale_sq"] * (1.0 + 0.25 * s)
+        h["amp"] = hyp["amp"] * (1.0 + 0.1 * s)
+        hyps.append(h)
+    return hyps
+
+
+@pytest.mark.parametrize("kind,d,N,M,obj,S", [("ei", 2, 24, 256, B.braninhoo, 3), ("cb", 6, 256, 32768, B.hartmann6, 4),
+                                              ("ei", 32, 192, 8192, B.ackley, 10), ("ei", 6, 2100, 1500, B.hartmann6, 2)])
+def test_eval_nominate_is_the_per_sample_loop_in_one_call(ctx, orc, kind, d, N, M, obj, S):
+    """b7_eval_nominate (bots/bayesopt.lua:56-99 as one call, one host synchronisation) against the separate entry
+    points: same winner, same value, the same accumulator bit for bit -- and the oracle's winner.  N = 2100 runs the
+    launch schedule (Npad > 2048), the others the persistent one."""
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, d, N, M, obj)
+    hyps = _marg_hyps(hyp, S)
+    ctx.grid_upload(X_hid)
+    val0, idx0, scores0 = _hip_nominate(ctx, X_obs, Y, hyps, kind)
+    ctx.gp_set_data(X_obs, Y)
+    kw = {"score": "ei", "fmin": [float(Y.min())]} if kind == "ei" else {"score": "cb"}
+    val1, idx1, rep = ctx.eval_nominate(hyps, want_report=True, **kw)
+    _, _, scores1 = ctx.score_finish(1.0, download=True)       # the accumulator holds score / S
+    assert (val1, idx1) == (val0, idx0)
+    assert np.array_equal(scores1, scores0)
+    assert not rep["jitter"].any() and not rep["info"].any()
+    if N <= 300:
+        want = _oracle_nominate(orc, X_obs, Y, X_hid, hyps, kind)
+        assert idx1 == orc.c.argmax_first(want)[0]
+    # a row offset only shifts the index (what a shard passes)
+    assert ctx.eval_nominate(hyps, global_row_offset=1000, **kw) == (val0, idx0 + 1000)
+
+
+def test_eval_nominate_redoes_the_nomination_when_a_pivot_fails(ctx, orc):
+    """One of the S hyper samples makes K singular (duplicate rows, no noise): its report says so after the fact, the
+    speculative scores are thrown away and the nomination is redone with utils/math.lua:159-218's jitter schedule --
+    the result the separate calls give."""
+    X = orc.c.sobol(300, 3, 1)
+    X[7] = X[3]
+    X[250] = X[100]
+    Y = np.sin(3.0 * X).sum(axis=1, keepdims=True)
+    X_hid = orc.c.sobol(4000, 3, 400)
+    good = dict(lenscale_sq=np.full(3, 0.4), amp=1.0, noise=1e-3, mean=0.1)
+    bad = dict(lenscale_sq=np.full(3, 0.4), amp=1.0, noise=0.0, mean=0.0)
+    hyps = [good, bad, dict(good, amp=1.3)]
+    ctx.grid_upload(X_hid)
+    for kind in ("ei", "cb"):
+        val0, idx0, scores0 = _hip_nominate(ctx, X, Y, hyps, kind)
+        ctx.gp_set_data(X, Y)
+        kw = {"score": "ei", "fmin": [float(Y.min())]} if kind == "ei" else {"score": "cb"}
+        val1, idx1, rep = ctx.eval_nominate(hyps, want_report=True, **kw)
+        _, _, scores1 = ctx.score_finish(1.0, download=True)
+        assert (val1, idx1) == (val0, idx0) and np.array_equal(scores1, scores0)
+        assert rep["jitter"][1] > 0 and rep["info"][1] > 0 and rep["jitter"][0] == 0 == rep["jitter"][2]
+
+
+def test_eval_nominate_survives_a_hand_off_time_out(orc, monkeypatch):
+    """Fault injection as in test_persistent_cholesky_times_out_into_the_launch_schedule, through the one-call path:
+    the speculative pass sees the abort in the reports, the redo runs the launch schedule, the result is unchanged."""
+    monkeypatch.setenv("B7_PERSIST_FAULT", "2")
+    launch, persist = _two_schedules(monkeypatch)
+    monkeypatch.delenv("B7_PERSIST_FAULT")
+    try:
+        X_obs, Y, X_hid, hyp = make_problem(None, orc, 6, 500, 3000, B.hartmann6)
+        hyps = _marg_hyps(hyp, 3)
+        out = []
+        for c in (launch, persist):
+            c.grid_upload(X_hid)
+            c.gp_set_data(X_obs, Y)
+            v, i = c.eval_nominate(hyps, score="ei", fmin=[float(Y.min())])
+            out.append((v, i, c.score_finish(1.0, download=True)[2]))
+        assert out[0][:2] == out[1][:2] and np.array_equal(out[0][2], out[1][2])
+        assert _aborts(persist) >= 1 and _aborts(launch) == 0
+    finally:
+        launch.close()
+        persist.close()
+
+
+def test_eval_nominate_argument_errors(ctx, orc):
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 3, 40, 100, lambda X: np.sin(X).sum(axis=1, keepdims=True))
+    ctx.grid_upload(X_hid)
+    ctx.gp_set_data(X_obs, Y)
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.eval_nominate([], score="cb")                                    # S >= 1
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.eval_nominate([hyp], score="ei")                                 # EI needs fmin
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.eval_nominate([dict(hyp, amp=-1.0)], score="cb")                 # amp > 0
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.eval_nominate([hyp], score="cb", global_row_offset=-1)
+    ctx.grid_upload(orc.c.sobol(50, 5))
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.eval_nominate([hyp], score="cb")                                 # grid dims != data dims
+    ctx.grid_upload(X_hid)
+    v, i = ctx.eval_nominate([hyp], score="cb")
+    assert 1 <= i <= 100 and np.isfinite(v)
+
+
 def test_bayesopt_driver_cfg1_plumbing(ctx, orc):
     """BASELINE config 1: braninhoo 2-D, GP+EI, 256-point grid, 25 trials, through the bots.bayesopt mirror;
     every nomination is re-derived with the oracle from the same observed set."""

@@ -66,10 +66,12 @@ def calls(src):
 
 def test_cdef_block_is_the_header():
     src = open(os.path.join(LUA, "bot7hip_ffi.lua")).read()
-    block = src.split("-- BEGIN generated from include/bot7hip.h (tools/gen_lua_cdef.py)\n")[1].split("-- END generated")[0]
+    block = src.split(gen_lua_cdef.BEGIN_CDEF)[1].split(gen_lua_cdef.END_CDEF)[0]
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", src, flags=re.S).group(1)
+    assert "--" not in cdef, "the cdef string is parsed as C: no Lua comments inside it"
     assert block.strip().splitlines() == gen_lua_cdef.cdef_lines(HEADER), \
         "lua/bot7hip_ffi.lua is out of date: regenerate the cdef block with tools/gen_lua_cdef.py"
-    consts = src.split("-- BEGIN generated constants\n")[1].split("-- END generated constants")[0]
+    consts = src.split(gen_lua_cdef.BEGIN_CONST)[1].split(gen_lua_cdef.END_CONST)[0]
     want = ["M.%s = %d" % (k[3:], v) for k, v in gen_lua_cdef.defines(HEADER).items()]
     assert consts.strip().splitlines() == want
 
@@ -81,7 +83,6 @@ def test_every_ffi_call_matches_a_declared_prototype():
     for f in lua_files():
         src = strip_lua_comments(open(os.path.join(LUA, f)).read())
         if f == "bot7hip_ffi.lua":
-            src = src.split("-- END generated")[-1] if "-- END generated" in src else src
             src = re.sub(r"ffi\.cdef\[\[.*?\]\]", "", open(os.path.join(LUA, f)).read(), flags=re.S)
             src = strip_lua_comments(src)
         for name, nargs in calls(src):
@@ -92,7 +93,7 @@ def test_every_ffi_call_matches_a_declared_prototype():
     # the entry points the driver's protocol needs are all reached from some shim
     for must in ("b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_remove_rows", "b7_gp_set_data",
                  "b7_gp_fit_hyp", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_score_reset", "b7_score_ei",
-                 "b7_score_cb", "b7_score_finish", "b7_score_finish_global", "b7_comm_unique_id", "b7_comm_init",
+                 "b7_score_cb", "b7_score_finish", "b7_score_finish_global", "b7_eval_nominate", "b7_comm_unique_id", "b7_comm_init",
                  "b7_blr_fit_x", "b7_blr_basis", "b7_blr_predict"):
         assert must in seen, "no Lua shim calls %s" % must
 
@@ -106,6 +107,13 @@ def test_shims_speak_the_driver_protocol():
     assert "bot7.samplers" in gp and "self.sampler.sample(" in gp and "log_posterior" in gp   # samplers/slice.lua drives nll
     # several chains in lock step: the reference's sampler inside coroutines, densities through b7_gp_nll_batch
     assert "coroutine.yield(" in gp and "coroutine.resume(" in gp and "self:nll_batch(X_obs, Y_obs, hyps)" in gp
+    # the fused nomination keeps the parent's sampling calls (bots/bayesopt.lua:68,74-75) and its random start (:90-91)
+    bt = strip_lua_comments(open(os.path.join(LUA, "bots_bayesopt_hip.lua")).read())
+    assert re.search(r"torch\.class\(title, parent\)", bt) and "'bot7.bots.bayesopt'" in bt
+    assert "model:sample_hypers(X_obs, Y_obs)" in bt and "model:sample_hypers(X_obs, Y_obs, nil, nil, true)" in bt
+    assert "self.nTrials <= self.config.bot.nInitial" in bt and "parent.nominate(self, candidates)" in bt
+    for meth in ("stage", "stage_data"):
+        assert re.search(r"function model:%s\(" % meth, gp), meth
     sc = strip_lua_comments(open(os.path.join(LUA, "scores_hip.lua")).read())
     assert re.search(r"model:fantasize\(config\.nFantasies,\s*X_obs,\s*Y_obs,\s*X_pend,\s*hyp\)", sc)
     assert "X_obs:cat(X_pend, 1)" in sc and "repeatTensor(1, config.nFantasies):cat(Y_pend, 1)" in sc

@@ -1,0 +1,69 @@
+// Probe: both large-grid posterior kernels on synthetic operands against the host model of v_mfma_f64_16x16x4_f64
+// (an ascending fma chain on C, profiles/..., tools/mfma_acc_probe.hip): which kernel reproduces
+//   v[n][c] = fma-chain_{k = 0..} Linv[n][k] * ks[c][k],  ss[c] = the kernel's fixed-order sum of squares
+// bit for bit?  (diagnostic tool, not product; includes the kernel source directly)
+#include "../bot7_amd/csrc/posterior.hip"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+int main(int argc, char **argv) {
+  const int Npad = argc > 1 ? atoi(argv[1]) : 128, nnz = argc > 2 ? atoi(argv[2]) : 5, row_lo = argc > 3 ? atoi(argv[3]) : 0;
+  const int M = 256;
+  std::vector<double> L((size_t)Npad * Npad, 0.0), K((size_t)M * Npad, 0.0), V4(M), V8(M);
+  srand(3);
+  for (int n = row_lo; n < nnz; ++n)
+    for (int k = 0; k <= n; ++k) L[(size_t)n * Npad + k] = rand() / (double)RAND_MAX - 0.5;
+  for (int c = 0; c < M; ++c)
+    for (int k = 0; k < nnz; ++k) K[(size_t)c * Npad + k] = rand() / (double)RAND_MAX - 0.5;
+  double *dL, *dK, *dV;
+  hipMalloc(&dL, L.size() * 8); hipMalloc(&dK, K.size() * 8); hipMalloc(&dV, M * 8);
+  hipMemcpy(dL, L.data(), L.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dK, K.data(), K.size() * 8, hipMemcpyHostToDevice);
+  {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(w4::post_kernel_w4), hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
+    hipLaunchKernelGGL(w4::post_kernel_w4, dim3(1), dim3(256), w4::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    hipDeviceSynchronize();
+    hipMemcpy(V4.data(), dV, M * 8, hipMemcpyDeviceToHost);
+  }
+  {
+    using GP = GemmF64<128, 256, 16, 2, 4, false, 1>;
+    auto kern = post_kernel<128, 256, 2, 4, 2, 1, true, true>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GP::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(512), GP::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    hipDeviceSynchronize();
+    hipMemcpy(V8.data(), dV, M * 8, hipMemcpyDeviceToHost);
+  }
+  // host model: per candidate c, rows n: v = ascending fma chain over k; squares folded in the kernels' order:
+  // lane group g = 0..3 holds rows 16 I + g + 4 r; per 128-row tile and half h: s = sum_{I in half} sum_r v^2 (fma chain),
+  // colss[h] += s; then (g0 + g1) + (g2 + g3) per half, then half0 + half1
+  int bad4 = 0, bad8 = 0, bad48 = 0;
+  for (int c = 0; c < M; ++c) {
+    double colss[2][4] = {};
+    for (int t = 0; t < Npad / 128; ++t)
+      for (int h = 0; h < 2; ++h)
+        for (int g = 0; g < 4; ++g) {
+          double s = 0.0;
+          for (int I = 4 * h; I < 4 * h + 4; ++I)
+            for (int r = 0; r < 4; ++r) {
+              const int n = t * 128 + 16 * I + g + 4 * r;
+              double v = 0.0;
+              for (int k = 0; k < Npad; ++k) v = __builtin_fma(L[(size_t)n * Npad + k], K[(size_t)c * Npad + k], v);
+              s = __builtin_fma(v, v, s);
+            }
+          colss[h][g] += s;
+        }
+    double hv[2];
+    for (int h = 0; h < 2; ++h) {
+      double a = colss[h][0] + colss[h][1], b = colss[h][2] + colss[h][3];
+      hv[h] = a + b;
+    }
+    double ss = hv[0];
+    ss += hv[1];
+    bad4 += memcmp(&ss, &V4[c], 8) != 0;
+    bad8 += memcmp(&ss, &V8[c], 8) != 0;
+    bad48 += memcmp(&V4[c], &V8[c], 8) != 0;
+  }
+  printf("Npad %d, rows [%d, %d) nonzero: host model vs w4: %d of %d differ; vs w8: %d; w4 vs w8: %d\n", Npad, row_lo, nnz, bad4, M, bad8, bad48);
+  return 0;
+}
