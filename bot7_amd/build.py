@@ -40,19 +40,81 @@ def _compile(src):
     return obj, False
 
 
+def posterior_isa():
+    """The device ISA of posterior.hip as text (same compiler, same flags as the object that ships), cached."""
+    out = os.path.join(BUILD, "posterior.s")
+    path = os.path.join(CSRC, "posterior.hip")
+    if _stale(out, [path] + HEADERS + [os.path.abspath(__file__)]):
+        subprocess.check_call([HIPCC] + [f for f in FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
+                                                                            path, "-o", out])
+    return out
+
+
+def check_agpr_discipline():
+    """post_kernel_w4 keeps its 32 accumulator tiles in a0..a255 BY NUMBER inside inline asm; the compiler is told so
+    only through clobber lists.  The build fails unless, in the ISA that ships, for both instantiations (1) no
+    instruction outside those asm statements names an AGPR, (2) the kernel has no scratch, and (3) every accumulator tile
+    is started from the literal 0 and read back.  Returns the counts per NJ."""
+    import re
+    text = open(posterior_isa()).read()
+    found = {}
+    for m in re.finditer(r"^(_ZN\S*post_kernel_w4ILi(\d)E\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M):
+        nj = int(m.group(2))
+        in_asm, stats, bad = False, {"mfma": 0, "mfma_from_zero": 0, "acc_reads": 0, "scratch": 0}, []
+        for line in m.group(3).split("\n"):
+            code = line.split(";")[0]
+            if "ASMSTART" in line:
+                in_asm = True
+                continue
+            if "ASMEND" in line:
+                in_asm = False
+                continue
+            if in_asm:
+                stats["mfma"] += "v_mfma_f64_16x16x4_f64" in code
+                stats["mfma_from_zero"] += bool(re.search(r"v_mfma_f64_16x16x4_f64 a\[[^\]]*\], v\[[^\]]*\], v\[[^\]]*\], 0\s*$", code))
+                stats["acc_reads"] += "v_accvgpr_read_b32" in code
+            else:
+                if re.search(r"(?<![A-Za-z0-9_.])a(\[|\d)", code):
+                    bad.append(line.strip())
+                stats["scratch"] += "scratch_" in code
+        if bad or stats["scratch"] or stats["mfma_from_zero"] != 8 * nj or stats["acc_reads"] != 64 * nj:
+            raise RuntimeError("post_kernel_w4<%d>: AGPR discipline broken: %r, compiler-generated AGPR uses: %r"
+                               % (nj, stats, bad[:5]))
+        found[nj] = stats
+    if sorted(found) != [2, 4]:
+        raise RuntimeError("post_kernel_w4<2> and <4> expected in the ISA of posterior.hip, found %r" % sorted(found))
+    return found
+
+
+def build_post_probe():
+    """tools/_build/post_probe: both large-grid posterior kernels on synthetic operands against the host model of the
+    arithmetic (ascending fma chains, fixed fold order); tests/test_gpu_parity.py runs it on the GPU box."""
+    src = os.path.join(ROOT, "tools", "post_probe.hip")
+    out = os.path.join(ROOT, "tools", "_build", "post_probe")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if _stale(out, [src, os.path.join(ROOT, "tools", "post_kernel_w8.h"), os.path.join(CSRC, "posterior.hip")] + HEADERS):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-Wno-unused-value",
+                               "-DB7_POST_NO_LAUNCHERS", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                               "-I/opt/rocm/include", "-o", out, src, "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(BUILD, exist_ok=True)
     if force:
         for f in os.listdir(BUILD):
             os.remove(os.path.join(BUILD, f))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(SOURCES) + 1)) as ex:
+        isa = ex.submit(check_agpr_discipline)
         results = list(ex.map(_compile, SOURCES))
+        isa.result()
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or _stale(OUT, objs):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs +
                               ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
         if verbose:
             print("built", OUT)
+    build_post_probe()
     return OUT
 
 

@@ -130,7 +130,6 @@ int b7_create(b7_ctx **out, int device_id) {
   c->cus = prop.multiProcessorCount;
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
-  if (const char *pv = getenv("B7_POST_SHAPE")) c->post_shape = atoi(pv) == 8 ? 8 : 4;  // A/B of the large-grid posterior kernel
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always

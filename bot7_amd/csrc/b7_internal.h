@@ -42,7 +42,6 @@ struct b7_ctx {
   hipEvent_t ev_fit = nullptr;  // behind the fit report's copy: b7_gp_predict_hyp waits for it, not for the prediction
   std::string err;
   int cus = 0;
-  int post_shape = 4;  // waves of the large-grid posterior kernel: 4 (one per SIMD, pipelined) or 8 (B7_POST_SHAPE=8)
 
   // ---- candidate grid (row-major M x d), ping-pong for stable row removal
   DevBuf grid[2];

@@ -5,21 +5,29 @@
 // the absent `gp` package): textbook GP regression, V = L^-1 K(X*,X)', var = k** - colsumsq(V).
 //
 // This is the dominant kernel of the whole path: M * N^2 flops (4.19 MFLOP per candidate at N = 2048), all
-// of it on v_mfma_f64_16x16x4_f64.  V is never stored: a block owns 128 candidates, walks the 128-row
-// tiles of the explicit inverse factor top to bottom (k only up to the diagonal: Linv is lower triangular)
-// and folds each finished 128x128 tile of V into per-candidate sums of squares held in registers.
-// The summation order is fixed (n-tiles ascending, then a fixed shuffle/LDS tree), so results are bitwise
-// reproducible run to run -- the arg-max downstream depends on that.
+// of it on v_mfma_f64_16x16x4_f64.  V is never stored: a workgroup owns 256 (large grids) or 128 (small grids)
+// candidates, walks the 128-row tiles of the explicit inverse factor top to bottom (k only up to the diagonal: Linv
+// is lower triangular) and folds each finished tile of V into per-candidate sums of squares held in registers.
 //
-// How the tile shape was chosen (A/B in one process on MI355X, N = 2048, 262144 candidates, round 1; all variants
-// bitwise identical): 128x128 tile, 1 wave/SIMD 44.6 TF | 2 blocks/CU 59.2 | + odd LDS stride 59.7 | + zero-strip skip
-// 61.3 | both 61.6 | both on a 128(n) x 256(cand) tile with 8 waves 63.6 | + static priority 64.7 TF = 82 % of 78.6.
-// PMC: MFMA pipe 84 % busy, effective clock 2.1 GHz (DVFS) -> 68 TF is the ceiling at that clock.
+// The arithmetic is fixed, and stated so that a host model can reproduce it bit for bit (tools/post_probe.hip does):
+//   v[n][c]  = fma chain over k ascending of Linv[n][k] * K*[c][k]     (what a chain of v_mfma_f64_16x16x4_f64 computes,
+//              tools/mfma_acc_probe.hip)
+//   per lane group g = 0..3, 128-row tile t and row half h:  s = fma chain of v^2 over rows 16 I + g + 4 r  (I in the
+//              half ascending, r ascending), colss[h] += s over t ascending
+//   ss[c]    = ((g0 + g1) + (g2 + g3))_{h=0} + (...)_{h=1}
+// so results do not depend on the grid size, the shard layout or the run -- the arg-max downstream relies on that.
+//
+// Shape history (N = 2048, 262144 candidates per launch, one MI355X): round 1, compiler-scheduled GEMM tile loop,
+// 128 x 128 tile 44.6 TF -> 2 blocks/CU 59.2 -> odd LDS stride, zero-strip skip 61.6 -> 128 x 256 tile with 8 waves and
+// a static priority raise 64.7 TF.  Round 2: in-kernel stamps (tools/post_clock.py: s_memtime / s_memrealtime around
+// every workgroup after >= 2 s of back-to-back launches) showed the chip holding 2.37 GHz -- not the 2.1 GHz round 1
+// had inferred from counters -- and the workgroup NOT issuing MFMAs for 14 % of its cycles: the two waves of a SIMD
+// run in lock step, sit in the same LDS wait at mid-stage and at the barrier, and 256 registers per wave leave no room
+// to fetch fragments ahead.  The kernel below: 96.4 % issue efficiency at 2.31 GHz, 71.7 TF = 91 % of the 78.6 TF peak.
 //
 // Algorithmic work per launch: rows * Npad^2 flops (triangle exploited), bytes: the K* chunk is read
-// (t+1)/T-weighted ~ (T+1)/2 times from L2/MALL/HBM (T = Npad/128 n-tiles), Linv once per block from L2.
+// (t+1)/T-weighted ~ (T+1)/2 times from L2/MALL/HBM (T = Npad/128 n-tiles), Linv once per workgroup from L2.
 #include "b7_internal.h"
-#include "gemm_f64.h"
 #include <utility>
 
 #ifdef B7_POST_STAMPS
@@ -32,103 +40,31 @@ extern "C" int b7dbg_post_stamps(unsigned long long *out, int nblocks) {
 }
 #endif
 
-namespace {
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
-// BM = rows of L^-1 per n-tile, BN = candidates per block, WM x WN waves of 64x64 accumulators each.
-template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI, bool PRIO = false>
-__global__ void __launch_bounds__(64 * WM * WN, MINW)
-    post_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0,
-                int64_t Mtotal, double base, double sgn, double var_add, int clamp, double var_min,
-                double *__restrict__ var) {
-  using GP = GemmF64<BM, BN, 16, WM, WN, false, PAD>;
-  static_assert(GP::TM == 4 && GP::TN == 4, "64x64 per wave");
-  extern __shared__ __align__(16) double sm[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double *B = ks + (int64_t)blockIdx.x * BN * Npad;  // this block's BN candidate rows of K*
-#ifdef B7_POST_STAMPS
-  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
-  double colss[GP::TN] = {};
-  // PRIO: with two waves per SIMD the second-dispatched half of the workgroup loses issue arbitration to the older
-  // half at the start of every stage; one static priority raise for that half evens it out (the condition must be
-  // wave-uniform for the scalar s_setprio to be conditional at all)
-  if (PRIO && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 32 * WM * WN) __builtin_amdgcn_s_setprio(1);
-
-  const int ntiles = Npad / BM;
-  for (int t = 0; t < ntiles; ++t) {
-    d4_t acc[GP::TM][GP::TN] = {};
-    GP::template run<TRI>(Linv + (int64_t)t * BM * Npad, Npad, B, Npad, 0, (t + 1) * BM, acc, sm);
-#pragma unroll
-    for (int j = 0; j < GP::TN; ++j) {
-      double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < GP::TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[i][j][r], acc[i][j][r], s);  // explicit: the order is part of the result
-      colss[j] += s;
-    }
-  }
-
-  // lanes l, l^16, l^32, l^48 hold partial sums of the same candidate column; then the WM row-waves
-  double *red = sm;  // [WM][BN]; GP::run ended with a barrier, LDS is free
-  const int wm = wave / WN, wn = wave % WN;
-#pragma unroll
-  for (int j = 0; j < GP::TN; ++j) {
-    double v = colss[j];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (lane < 16) red[wm * BN + wn * 64 + j * 16 + lane] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < BN) {
-    const int64_t g = row0 + (int64_t)blockIdx.x * BN + threadIdx.x;
-    if (g < Mtotal) {
-      double ss = red[threadIdx.x];
-#pragma unroll
-      for (int w = 1; w < WM; ++w) ss += red[w * BN + threadIdx.x];
-      double v = (base + sgn * ss) + var_add;  // GP: amp - ss; Bayesian-linear head: 1/beta + ss
-      if (clamp) v = (v < var_min) ? var_min : v;  // TH clamp: NaN passes through
-      var[g] = v;
-    }
-  }
-#ifdef B7_POST_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x < 4096) {
-    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    unsigned long long *o = b7_post_stamps + 4 * blockIdx.x;
-    o[0] = st0, o[1] = sr0, o[2] = st1, o[3] = sr1;
-  }
-#endif
-}
-
-// ---- the large-grid shape: one wave per SIMD, one continuous MFMA stream ----------------------------------------------
-// Same block tile (128 rows of L^-1 x 256 candidates), same LDS image (16-deep stages, odd row stride), same
-// arithmetic bit for bit -- but FOUR waves of 128 x 64 instead of eight of 64 x 64.  In-kernel stamps of the 8-wave kernel
-// (tools/post_clock.py: s_memtime / s_memrealtime around every workgroup, >= 2 s of back-to-back launches) showed the
-// chip holding 2.37 GHz, not the 2.1 GHz round 1 inferred from counters, and the workgroup spending 14 % of its
-// cycles NOT issuing MFMAs: the two waves of a SIMD run in lock step, so both sit in the same LDS wait at mid-stage
-// and at the barrier, and 256 registers per wave leave no room to fetch fragments ahead.  With 512 registers a wave
-// keeps two fragment sets and the next stage's global data in flight:
+// ---- one wave per SIMD, one continuous MFMA stream -----------------------------------------------------------------------
+// Four waves (512 registers each); a wave owns all 128 rows of the n-tile and 16 NJ candidates: 8 x NJ accumulator
+// tiles of 16 x 16 (NJ = 4: 128 x 256 workgroup tile; NJ = 2: 128 x 128, for grids with fewer than one 256-candidate
+// workgroup per CU).  LDS image of a stage: [128 + 64 NJ][16 + 1] doubles (odd row stride: ds_read2_b64 fragment
+// reads are conflict-free), two buffers.  A wave keeps two fragment sets and the next stage's global data in flight:
 //   first half of stage n  : MFMAs of k-steps 0,1 (set F0) | read F1 = k-steps 2,3 of stage n | store G (stage n+1,
 //                            loaded a stage ago) into the other LDS buffer | issue the global loads of stage n+2
 //   barrier (mid-stage)    : stage n+1's image is complete; nobody reads this stage's buffer any more
 //   second half of stage n : MFMAs of k-steps 2,3 (set F1) | read F0 = k-steps 0,1 of stage n+1
-// The stage stream runs across the n-tiles without a prologue per tile; in the 8 diagonal stages of a tile the 16-row
-// strips above the diagonal are skipped exactly as before.  Two LDS buffers suffice: every read of a buffer precedes the
-// mid-stage barrier of the stage after the one that computes from it, every write to it follows that barrier.
+// The side operations are placed between the MFMAs in program order (about one every second MFMA), so a wave never
+// waits on LDS or on memory, only on the barrier's skew.  The stage stream runs across the n-tiles without a
+// prologue per tile; in the 8 diagonal stages of a tile the 16-row strips above the diagonal are skipped.  Two LDS
+// buffers suffice: every read of a buffer precedes the mid-stage barrier of the stage after the one that computes from
+// it, every write to it follows that barrier.
 namespace w4 {
-constexpr int BM = 128, BN = 256, BK = 16, LD = BK + 1;
-constexpr int A_DBL = BM * LD, STAGE_DBL = (BM + BN) * LD;
-constexpr int LDS_BYTES = 2 * STAGE_DBL * 8;
+constexpr int BM = 128, BK = 16, LD = BK + 1, A_DBL = BM * LD;
 
-// The 32 accumulator tiles of a wave (8 strips of 16 rows x 4 strips of 16 candidates, 8 registers each) are the 256
-// AGPRs a0..a255, addressed by NUMBER inside inline asm and never held in a C++ variable: tile (i, j) is
-// a[8 (4 i + j) : 8 (4 i + j) + 7].  (As compiler-visible values -- the builtin, or "+a" asm operands -- the register
-// allocator carried some of them across the loop back-edge in VGPRs: hundreds of v_accvgpr copies per stage, spills, and
-// no hazard handling after an asm MFMA.)  Every asm statement below names all 256 as clobbered, so the compiler keeps
-// nothing of its own in them; tests/test_abi_and_host.py checks in the generated ISA that no instruction outside these
-// asm statements touches an AGPR.
+// The accumulator tiles of a wave are AGPRs addressed by NUMBER inside inline asm, never held in a C++ variable:
+// tile (i, j) is a[8 (NJ i + j) : 8 (NJ i + j) + 7].  (As compiler-visible values -- the builtin, or "+a" asm
+// operands -- the register allocator carried some of them across the loop back-edge in VGPRs: hundreds of v_accvgpr
+// copies per stage, spills, and no hazard handling after an asm MFMA.)  Every asm statement below names all 256 AGPRs as
+// clobbered, so the compiler keeps nothing of its own in them; bot7_amd/build.py checks in the ISA of every build that no
+// instruction outside these asm statements names an AGPR.
 #define B7_W4_ACC_REGS \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
   "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", \
@@ -150,9 +86,9 @@ constexpr int LDS_BYTES = 2 * STAGE_DBL * 8;
   "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", \
   "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 
-template <int I, int J, bool ZERO>
+template <int NJ, int I, int J, bool ZERO>
 __device__ __forceinline__ void mfma_tile(double a, double b) {
-  constexpr int lo = 8 * (4 * I + J);
+  constexpr int lo = 8 * (NJ * I + J);
   if constexpr (ZERO)
     asm volatile("v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, 0" ::"v"(a), "v"(b), "n"(lo), "n"(lo + 7) : B7_W4_ACC_REGS);
   else
@@ -160,10 +96,10 @@ __device__ __forceinline__ void mfma_tile(double a, double b) {
                  : B7_W4_ACC_REGS);
 }
 
-// sum of squares of accumulator tile (I, J): the caller has drained the matrix pipe (s_nop) before the first one
-template <int I, int J>
+// accumulator tile (I, J) back into VGPRs: the caller has drained the matrix pipe (s_nop) before the first one
+template <int NJ, int I, int J>
 __device__ __forceinline__ void read_tile(double (&v)[4]) {
-  constexpr int lo = 8 * (4 * I + J);
+  constexpr int lo = 8 * (NJ * I + J);
   unsigned w[8];
   asm volatile(
       "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\tv_accvgpr_read_b32 %2, a[%10]\n\t"
@@ -175,11 +111,13 @@ __device__ __forceinline__ void read_tile(double (&v)[4]) {
   for (int r = 0; r < 4; ++r) v[r] = __hiloint2double((int)w[2 * r + 1], (int)w[2 * r]);
 }
 
+template <int NJ>
 struct Frags {
-  double a[2][8], b[2][4];  // two k-steps: 8 strips of L^-1 rows, 4 strips of candidates
+  double a[2][8], b[2][NJ];  // two k-steps: 8 strips of L^-1 rows, NJ strips of candidates
 };
-struct Stage {  // global data of one stage in flight: 4 + 8 sixteen-byte chunks per thread
-  d2_t c[12];
+template <int NJ>
+struct Stage {  // global data of one stage in flight: 4 + 2 NJ sixteen-byte chunks per thread
+  d2_t c[4 + 2 * NJ];
 };
 struct Cursor {  // (n-tile, 16-deep k block) of a stage; clamps at the last stage
   int t, kb, ntiles;
@@ -202,58 +140,58 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
 }
 
-// fragment pair P of a two-k-step set: P < 4 candidates strip P, else rows strip P - 4 (k-steps s0, s0 + 1)
-template <int P, int S0>
-__device__ __forceinline__ void read_pair(Frags &f, const double *__restrict__ sa, const double *__restrict__ sb) {
-  if constexpr (P < 4) {
+// fragment pair P of a two-k-step set: P < NJ candidates strip P, else rows strip P - NJ (k-steps S0, S0 + 1)
+template <int NJ, int P, int S0>
+__device__ __forceinline__ void read_pair(Frags<NJ> &f, const double *__restrict__ sa, const double *__restrict__ sb) {
+  if constexpr (P < NJ) {
     f.b[0][P] = sb[P * 16 * LD + 4 * S0];
     f.b[1][P] = sb[P * 16 * LD + 4 * S0 + 4];
   } else {
-    f.a[0][P - 4] = sa[(P - 4) * 16 * LD + 4 * S0];
-    f.a[1][P - 4] = sa[(P - 4) * 16 * LD + 4 * S0 + 4];
+    f.a[0][P - NJ] = sa[(P - NJ) * 16 * LD + 4 * S0];
+    f.a[1][P - NJ] = sa[(P - NJ) * 16 * LD + 4 * S0 + 4];
   }
 }
 
 // chunk C of a stage: C < 4 rows r0 + 32 C of the L^-1 tile, else candidates r0 + 32 (C - 4) of the K* tile
-template <int C>
-__device__ __forceinline__ void load_chunk(Stage &g, const double *__restrict__ qa, const double *__restrict__ qb,
+template <int NJ, int C>
+__device__ __forceinline__ void load_chunk(Stage<NJ> &g, const double *__restrict__ qa, const double *__restrict__ qb,
                                            int64_t lda) {
   if constexpr (C < 4)
     g.c[C] = *reinterpret_cast<const d2_t *>(qa + (int64_t)(32 * C) * lda);
   else
     g.c[C] = *reinterpret_cast<const d2_t *>(qb + (int64_t)(32 * (C - 4)) * lda);
 }
-template <int C>
-__device__ __forceinline__ void store_chunk(const Stage &g, double *__restrict__ w) {
+template <int NJ, int C>
+__device__ __forceinline__ void store_chunk(const Stage<NJ> &g, double *__restrict__ w) {
   constexpr int o = C < 4 ? 32 * C * LD : A_DBL + 32 * (C - 4) * LD;
   w[o] = g.c[C][0];
   w[o + 1] = g.c[C][1];
 }
 
 // One stage of the stream.  FIRST = first 16-row strip with anything to do (0 away from the diagonal block); ZERO: the
-// first stage of an n-tile starts the accumulators from zero.  NM MFMAs per half; the side operations of a half (first:
-// 12 fragment pairs of F1, 12 LDS stores of the next stage, 12 global loads of the one after; second: 12 fragment pairs
-// of the next stage's F0) are spread evenly between them, one every second MFMA away from the diagonal.
-template <int FIRST, bool ZERO>
-__device__ __forceinline__ void stage(Frags &f0, Frags &f1, Stage &g, double *__restrict__ cur, double *__restrict__ nxt,
-                                      int fa, int fb, int wofs, const double *__restrict__ pa,
+// first stage of an n-tile starts the accumulators from the literal 0.  NM MFMAs per half; the side operations of a half
+// (first: the fragment pairs of F1, the LDS stores of the next stage, the global loads of the one after; second: the
+// fragment pairs of the next stage's F0) are spread evenly between them.
+template <int NJ, int FIRST, bool ZERO>
+__device__ __forceinline__ void stage(Frags<NJ> &f0, Frags<NJ> &f1, Stage<NJ> &g, double *__restrict__ cur,
+                                      double *__restrict__ nxt, int fa, int fb, int wofs, const double *__restrict__ pa,
                                       const double *__restrict__ pb, int64_t lda, Cursor &ld) {
-  constexpr int NI = 8 - FIRST, NM = 2 * 4 * NI;
+  constexpr int NI = 8 - FIRST, NM = 2 * NJ * NI, NP = 8 + NJ, NC = 4 + 2 * NJ, NS = NP + 2 * NC;
   const double *qa = pa + ((int64_t)ld.t * BM) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
   ld.advance();
   // ---- first half: k-steps 0, 1 from F0
   static_for<NM>([&](auto m_) {
-    constexpr int m = decltype(m_)::value, ks = m / (4 * NI), i = FIRST + (m % (4 * NI)) / 4, j = m % 4;
-    mfma_tile<i, j, ZERO && ks == 0>(f0.a[ks][i], f0.b[ks][j]);
-    static_for<36>([&](auto s_) {
+    constexpr int m = decltype(m_)::value, ks = m / (NJ * NI), i = FIRST + (m % (NJ * NI)) / NJ, j = m % NJ;
+    mfma_tile<NJ, i, j, ZERO && ks == 0>(f0.a[ks][i], f0.b[ks][j]);
+    static_for<NS>([&](auto s_) {
       constexpr int sidx = decltype(s_)::value;
-      if constexpr (sidx >= m * 36 / NM && sidx < (m + 1) * 36 / NM) {
-        if constexpr (sidx < 12) {
-          if constexpr (sidx < 4 || sidx - 4 >= FIRST) read_pair<sidx, 2>(f1, cur + fa, cur + fb);
-        } else if constexpr (sidx < 24) {
-          store_chunk<sidx - 12>(g, nxt + wofs);
+      if constexpr (sidx >= m * NS / NM && sidx < (m + 1) * NS / NM) {
+        if constexpr (sidx < NP) {
+          if constexpr (sidx < NJ || sidx - NJ >= FIRST) read_pair<NJ, sidx, 2>(f1, cur + fa, cur + fb);
+        } else if constexpr (sidx < NP + NC) {
+          store_chunk<NJ, sidx - NP>(g, nxt + wofs);
         } else {
-          load_chunk<sidx - 24>(g, qa, qb, lda);
+          load_chunk<NJ, sidx - NP - NC>(g, qa, qb, lda);
         }
       }
     });
@@ -262,18 +200,20 @@ __device__ __forceinline__ void stage(Frags &f0, Frags &f1, Stage &g, double *__
   __builtin_amdgcn_s_barrier();
   // ---- second half: k-steps 2, 3 from F1; the next stage's F0 (all strips: its FIRST is not known here)
   static_for<NM>([&](auto m_) {
-    constexpr int m = decltype(m_)::value, ks = m / (4 * NI), i = FIRST + (m % (4 * NI)) / 4, j = m % 4;
-    mfma_tile<i, j, false>(f1.a[ks][i], f1.b[ks][j]);
-    static_for<12>([&](auto s_) {
+    constexpr int m = decltype(m_)::value, ks = m / (NJ * NI), i = FIRST + (m % (NJ * NI)) / NJ, j = m % NJ;
+    mfma_tile<NJ, i, j, false>(f1.a[ks][i], f1.b[ks][j]);
+    static_for<NP>([&](auto s_) {
       constexpr int sidx = decltype(s_)::value;
-      if constexpr (sidx >= m * 12 / NM && sidx < (m + 1) * 12 / NM) read_pair<sidx, 0>(f0, nxt + fa, nxt + fb);
+      if constexpr (sidx >= m * NP / NM && sidx < (m + 1) * NP / NM) read_pair<NJ, sidx, 0>(f0, nxt + fa, nxt + fb);
     });
   });
 }
 
+template <int NJ>
 __global__ void __launch_bounds__(256)
     post_kernel_w4(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0, int64_t Mtotal,
                    double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var) {
+  constexpr int BN = 64 * NJ, STAGE_DBL = (BM + BN) * LD, NC = 4 + 2 * NJ, NP = 8 + NJ;
   extern __shared__ __align__(16) double sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef B7_POST_STAMPS
@@ -288,30 +228,30 @@ __global__ void __launch_bounds__(256)
   const int wofs = r0 * LD + 2 * kc;
   // fragments: lane -> (row or candidate lane & 15 of a strip, k = 4 s + (lane >> 4))
   const int fa = (lane & 15) * LD + (lane >> 4);
-  const int fb = A_DBL + (wave * 64 + (lane & 15)) * LD + (lane >> 4);
+  const int fb = A_DBL + (wave * 16 * NJ + (lane & 15)) * LD + (lane >> 4);
 
   const int ntiles = Npad / BM;
   Cursor ld{0, 0, ntiles};
-  Stage g;
-  Frags f0, f1;
+  Stage<NJ> g;
+  Frags<NJ> f0, f1;
   double *const b0 = sm, *const b1 = sm + STAGE_DBL;  // every tile has an even number of stages: it starts on b0
-  static_for<12>([&](auto c_) { load_chunk<decltype(c_)::value>(g, pa, pb, lda); });  // stage 0
+  static_for<NC>([&](auto c_) { load_chunk<NJ, decltype(c_)::value>(g, pa, pb, lda); });  // stage 0
   ld.advance();
-  static_for<12>([&](auto c_) { store_chunk<decltype(c_)::value>(g, b0 + wofs); });
+  static_for<NC>([&](auto c_) { store_chunk<NJ, decltype(c_)::value>(g, b0 + wofs); });
   {
     const double *qa = pa + ((int64_t)ld.t * BM) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
-    static_for<12>([&](auto c_) { load_chunk<decltype(c_)::value>(g, qa, qb, lda); });  // stage 1: stored during stage 0
+    static_for<NC>([&](auto c_) { load_chunk<NJ, decltype(c_)::value>(g, qa, qb, lda); });  // stage 1: stored during stage 0
     ld.advance();
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
-  static_for<12>([&](auto p_) { read_pair<decltype(p_)::value, 0>(f0, b0 + fa, b0 + fb); });
+  static_for<NP>([&](auto p_) { read_pair<NJ, decltype(p_)::value, 0>(f0, b0 + fa, b0 + fb); });
 
-  double colss[2][4] = {};  // rows 0..63 and 64..127 of every n-tile apart: the summation order of the 8-wave shapes
-#define B7_STAGE(F, Z, CUR, NXT) stage<F, Z>(f0, f1, g, CUR, NXT, fa, fb, wofs, pa, pb, lda, ld)
+  double colss[2][NJ] = {};  // rows 0..63 and 64..127 of every n-tile apart
+#define B7_STAGE(F, Z, CUR, NXT) stage<NJ, F, Z>(f0, f1, g, CUR, NXT, fa, fb, wofs, pa, pb, lda, ld)
   for (int t = 0; t < ntiles; ++t) {
     // 8 t stages away from the diagonal block, then its 8 stages (in stage q the strips 0..q-1 hold zeros only); the
-    // tile's first stage zeroes the accumulators; buffers alternate, b0 first
+    // tile's first stage starts the accumulators from zero; buffers alternate, b0 first
     B7_STAGE(0, true, b0, b1);
     if (t > 0) {
       for (int p = 0; p < 4 * t - 1; ++p) {
@@ -330,14 +270,14 @@ __global__ void __launch_bounds__(256)
     B7_STAGE(7, false, b1, b0);
     // the asm MFMAs are opaque to the compiler's hazard recogniser: drain the matrix pipe before VALU reads the tile
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    static_for<8>([&](auto hj_) {
-      constexpr int h = decltype(hj_)::value / 4, j = decltype(hj_)::value % 4;
+    static_for<2 * NJ>([&](auto hj_) {
+      constexpr int h = decltype(hj_)::value / NJ, j = decltype(hj_)::value % NJ;
       double s = 0.0;
       static_for<4>([&](auto i_) {
         double v[4];
-        read_tile<4 * h + decltype(i_)::value, j>(v);
+        read_tile<NJ, 4 * h + decltype(i_)::value, j>(v);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s = __builtin_fma(v[r], v[r], s);
+        for (int r = 0; r < 4; ++r) s = __builtin_fma(v[r], v[r], s);  // explicit: the order is part of the result
       });
       colss[h][j] += s;
     });
@@ -346,18 +286,18 @@ __global__ void __launch_bounds__(256)
 
   // lanes l, l^16, l^32, l^48 hold partial sums of the same candidate; then the two row halves
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     double v0 = colss[0][j], v1 = colss[1][j];
     v0 += __shfl_xor(v0, 16);
     v0 += __shfl_xor(v0, 32);
     v1 += __shfl_xor(v1, 16);
     v1 += __shfl_xor(v1, 32);
-    const int64_t gidx = row0 + (int64_t)blockIdx.x * BN + wave * 64 + j * 16 + lane;
+    const int64_t gidx = row0 + (int64_t)blockIdx.x * BN + wave * 16 * NJ + j * 16 + lane;
     if (lane < 16 && gidx < Mtotal) {
       double ss = v0;
       ss += v1;
-      double v = (base + sgn * ss) + var_add;
-      if (clamp) v = (v < var_min) ? var_min : v;
+      double v = (base + sgn * ss) + var_add;  // GP: amp - ss; Bayesian-linear head: 1/beta + ss
+      if (clamp) v = (v < var_min) ? var_min : v;  // TH clamp: NaN passes through
       var[gidx] = v;
     }
   }
@@ -370,43 +310,32 @@ __global__ void __launch_bounds__(256)
   }
 #endif
 }
+
+template <int NJ>
+constexpr int lds_bytes() { return 2 * (BM + 64 * NJ) * LD * 8; }
 }  // namespace w4
 
-static int launch_post_w4(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(w4::post_kernel_w4),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES));
+#ifndef B7_POST_NO_LAUNCHERS
+namespace {
+template <int NJ>
+int launch_post_w4(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
+  constexpr int lds = w4::lds_bytes<NJ>();
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(w4::post_kernel_w4<NJ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const bool blr = c->model_kind == 1;
-  hipLaunchKernelGGL(w4::post_kernel_w4, dim3((unsigned)(rows / w4::BN)), dim3(256), w4::LDS_BYTES, c->stream,
+  hipLaunchKernelGGL(w4::post_kernel_w4<NJ>, dim3((unsigned)(rows / (64 * NJ))), dim3(256), lds, c->stream,
                      (const double *)c->Linv.p, ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
                      blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
-
-template <int BM, int BN, int WM, int WN, int MINW, int PAD, bool TRI, bool PRIO = false>
-int launch_post_variant(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
-  using GP = GemmF64<BM, BN, 16, WM, WN, false, PAD>;
-  auto kern = post_kernel<BM, BN, WM, WN, MINW, PAD, TRI, PRIO>;
-  const int lds = GP::LDS_BYTES;
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const bool blr = c->model_kind == 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / BN)), dim3(64 * WM * WN), lds, c->stream, (const double *)c->Linv.p,
-                     ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
-                     blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
-  B7_HIP(c, hipGetLastError());
-  return B7_OK;
-}
-
 }  // namespace
 
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
   PhaseScope ps(c, "post");
   if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
-  // Two shapes, bitwise identical in output (the A/B ladder that led here is in DESIGN.md section 8): 128(n) x 256(cand)
-  // tile with 8 waves, odd LDS stride, zero-strip skip and a static priority raise for the younger half of the waves;
-  // with fewer 256-candidate workgroups than CUs the 128-wide tile fills the chip (N = 2048, M = 32768: 2.6 vs 4.2 ms;
-  // N = 256: 63 vs 83 us; a 64-wide one was slower again, 4.1 ms)
-  if (rows / 256 < c->cus) return launch_post_variant<128, 128, 2, 2, 2, 1, true>(c, ks, row0, rows, Mtotal, var);
-  if (c->post_shape == 8) return launch_post_variant<128, 256, 2, 4, 2, 1, true, true>(c, ks, row0, rows, Mtotal, var);
-  return launch_post_w4(c, ks, row0, rows, Mtotal, var);
+  // 256 candidates per workgroup when that still gives every CU one; otherwise 128 (same arithmetic, same bits)
+  if (rows / 256 < c->cus) return launch_post_w4<2>(c, ks, row0, rows, Mtotal, var);
+  return launch_post_w4<4>(c, ks, row0, rows, Mtotal, var);
 }
+#endif

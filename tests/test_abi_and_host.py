@@ -217,3 +217,14 @@ def test_library_winner_rule_matches_th_max_for_any_world_size(orc):
     assert _lib.comm_pick_winner([(1.0, 0), (0.5, 7), (9.0, 0)]) == (0.5, 7)
     with pytest.raises(bot7_amd.Bot7HipError):
         _lib.comm_pick_winner([(1.0, 0), (2.0, 0)])
+
+
+def test_posterior_accumulators_stay_out_of_the_compilers_hands():
+    """post_kernel_w4 addresses its accumulators as a0..a255 by number inside inline asm.  In the ISA that ships no
+    compiler-generated instruction may name an AGPR, the kernel has no scratch, each of the 32 tiles is started once
+    from the literal 0 and all 256 registers are read back (bot7_amd/build.py runs the same check on every build)."""
+    from bot7_amd import build
+    stats = build.check_agpr_discipline()
+    for nj in (2, 4):   # 128- and 256-candidate workgroups
+        st = stats[nj]
+        assert st["mfma"] >= 34 * 8 * nj and st["mfma_from_zero"] == 8 * nj and st["acc_reads"] == 64 * nj and st["scratch"] == 0

@@ -379,32 +379,34 @@ def test_marginalised_argmax_matches_oracle(ctx, orc, kind, d, N, M, obj, S):
 
 
 @pytest.mark.parametrize("N,d,M", [(700, 6, 70000), (100, 3, 66000), (2048, 32, 65536 + 256)])
-def test_posterior_kernel_shapes_are_bit_identical(orc, monkeypatch, N, d, M):
-    """The large-grid posterior kernel (four waves of 128 x 64, accumulators in numbered AGPRs, one continuous MFMA
-    stream) against the eight-wave shape it replaced (B7_POST_SHAPE=8) and against the small-grid shape: same
-    variance bits for every candidate, and the oracle's values on a sample."""
-    import bot7_amd
+def test_posterior_grid_shapes_are_bit_identical(ctx, orc, N, d, M):
+    """256-candidate workgroups (grids with at least one per CU) and 128-candidate workgroups (smaller grids) give the
+    same variance bits for the same candidate, and the oracle's values on a sample."""
     X_obs, Y, X_hid, hyp = make_problem(None, orc, d, N, M, lambda X: np.sin(3.0 * X).sum(axis=1, keepdims=True))
-    out = []
-    for shape in ("4", "8"):
-        monkeypatch.setenv("B7_POST_SHAPE", shape)
-        c = bot7_amd.Context(0)
-        monkeypatch.delenv("B7_POST_SHAPE")
-        try:
-            c.grid_upload(X_hid)
-            c.gp_fit(X_obs, Y, **hyp)
-            out.append(c.gp_predict())
-            if shape == "4":                      # the small-grid shape: the same rows in a grid below one block per CU
-                c.grid_upload(X_hid[:4096])
-                small = c.gp_predict()
-        finally:
-            c.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    assert np.array_equal(out[0][1][:4096], small[1])
+    ctx.grid_upload(X_hid)
+    ctx.gp_fit(X_obs, Y, **hyp)
+    mu, var = ctx.gp_predict()
+    ctx.grid_upload(X_hid[:4096])           # fewer than one 256-candidate workgroup per CU
+    mu_s, var_s = ctx.gp_predict()
+    assert np.array_equal(var[:4096], var_s) and np.array_equal(mu[:4096], mu_s)
     f = orc.gp.fit(X_obs, Y, **hyp)
     idx = np.linspace(0, M - 1, 300).astype(int)
     mu_o, var_o = orc.gp.predict(f, X_hid[idx])
-    assert relerr(out[0][1][idx], var_o) < REL
+    assert relerr(var[idx], var_o) < REL
+
+
+def test_posterior_kernels_reproduce_the_host_model_bit_for_bit():
+    """tools/post_probe.hip: both workgroup shapes of the library's kernel, and the eight-wave kernel of earlier
+    rounds (tools/post_kernel_w8.h, not shipped), launched directly on synthetic L^-1 / K* operands against the host
+    model of their arithmetic -- v[n] = ascending fma chain over k (what v_mfma_f64_16x16x4_f64 does, tools/
+    mfma_acc_probe.hip), squares folded in the documented order -- for one tile, a ragged N and several tiles."""
+    import subprocess
+    from bot7_amd import build
+    exe = build.build_post_probe()
+    for args in (("128", "5"), ("128", "100"), ("256", "200"), ("768", "700"), ("2048", "2048")):
+        out = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "differing from the host model: w4<4> 0, w4<2> 0, w8 0" in out.stdout, out.stdout
 
 
 def _marg_hyps(hyp, S):
