@@ -104,17 +104,18 @@ def build(force=False, verbose=False):
     if force:
         for f in os.listdir(BUILD):
             os.remove(os.path.join(BUILD, f))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(SOURCES) + 1)) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES) + 2)) as ex:
         isa = ex.submit(check_agpr_discipline)
+        probe = ex.submit(build_post_probe)
         results = list(ex.map(_compile, SOURCES))
         isa.result()
+        probe.result()
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or _stale(OUT, objs):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs +
                               ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
         if verbose:
             print("built", OUT)
-    build_post_probe()
     return OUT
 
 

@@ -729,8 +729,7 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
 
   B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69
   c->acc_valid = true;
-  bool speculative = true;
-  for (int s = 0; s < S && speculative; ++s) {
+  for (int s = 0; s < S; ++s) {
     B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
     B7_TRY(launch_potrf(c, 0.0, true));
     if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it

@@ -443,6 +443,37 @@ def test_eval_nominate_is_the_per_sample_loop_in_one_call(ctx, orc, kind, d, N, 
     assert ctx.eval_nominate(hyps, global_row_offset=1000, **kw) == (val0, idx0 + 1000)
 
 
+def test_eval_nominate_with_fantasy_columns(ctx, orc):
+    """c > 1 response columns (the fantasies of scores/expected_improvement.lua:51-60): EI is the row mean over the
+    columns (:83-85); one call against the separate entry points and against the oracle."""
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 4, 150, 3000, lambda X: np.cos(2.0 * X).sum(axis=1, keepdims=True))
+    rng = np.random.default_rng(4)
+    Y3 = np.hstack([Y, Y + 0.05 * rng.normal(size=Y.shape), Y - 0.05 * rng.normal(size=Y.shape)])
+    hyps = _marg_hyps(hyp, 3)
+    fmin = Y3.min(axis=0)
+    ctx.grid_upload(X_hid)
+    first = True
+    for h in hyps:
+        ctx.gp_fit(X_obs, Y3, h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
+        ctx.gp_predict(download=False)
+        if first:
+            ctx.score_reset()
+            first = False
+        ctx.score_ei(fmin, 0.0)
+    val0, idx0, scores0 = ctx.score_finish(3.0, download=True)
+    ctx.gp_set_data(X_obs, Y3)
+    val1, idx1 = ctx.eval_nominate(hyps, score="ei", fmin=fmin)
+    _, _, scores1 = ctx.score_finish(1.0, download=True)
+    assert (val1, idx1) == (val0, idx0) and np.array_equal(scores1, scores0)
+    acc = np.zeros(X_hid.shape[0])
+    for h in hyps:
+        mu, var = orc.gp.predict(orc.gp.fit(X_obs, Y3, **h), X_hid)
+        orc.c.accumulate(acc, orc.c.ei(mu, var, fmin))
+    orc.c.divide(acc, 3.0)
+    assert np.max(np.abs(scores1 - acc)) < 1e-6 * max(1.0, np.abs(acc).max())
+    assert idx1 == orc.c.argmax_first(acc)[0]
+
+
 def test_eval_nominate_redoes_the_nomination_when_a_pivot_fails(ctx, orc):
     """One of the S hyper samples makes K singular (duplicate rows, no noise): its report says so after the fact, the
     speculative scores are thrown away and the nomination is redone with utils/math.lua:159-218's jitter schedule --
