@@ -55,19 +55,25 @@ def run(N=2048, d=32, M=1 << 18):
     ctx.timer_stop(0)
     wall_ms = ctx.timer_ms(0)
     L = _lib.load()
-    nb = min(4096, M // 256)
+    Npad = (N + 127) // 128 * 128
+    tall = Npad % 256 == 0                 # launch_post's rule for large grids (csrc/posterior.hip)
+    cand = 128 if tall else 256            # candidates per workgroup
+    nb = min(4096, M // cand)
     buf = (C.c_ulonglong * (4 * nb))()
     rc = L.b7dbg_post_stamps(buf, nb)
     assert rc == 0, rc
     a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.float64)
     cyc, ticks = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
     clk = cyc / ticks * 100e6
-    Npad = (N + 127) // 128 * 128
-    T = Npad // 128
-    # MFMAs per SIMD per workgroup of the 128 x 256 shape: full stages 128 each, the 8 diagonal stages of a tile 576 in all
-    mfma = sum(t * 8 * 128 + 576 for t in range(T))
+    # MFMAs per SIMD (= per wave) per workgroup: 128 per full 16-deep stage; in the diagonal block 16 x (strips left) per
+    # stage.  128 x 256 shape: n-tiles of 8 strips x 4 candidate strips; tall shape: 16 strips x 2
+    if tall:
+        mfma = sum(t * 16 * 128 + 4 * 2 * sum(16 - q for q in range(16)) for t in range(Npad // 256))
+    else:
+        mfma = sum(t * 8 * 128 + 4 * 4 * sum(8 - q for q in range(8)) for t in range(Npad // 128))
     need = mfma * 64.0
     print("launches before the stamped one: %d; fit + predict wall of the stamped pass %.3f ms" % (n, wall_ms))
+    print("shape: %s, %d candidates per workgroup, %d workgroups stamped" % ("256-row n-tiles" if tall else "128-row n-tiles", cand, nb))
     print("in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %d workgroups" % (np.median(clk) / 1e9, clk.min() / 1e9, clk.max() / 1e9, nb))
     print("workgroup duration: median %.1f us = %.3e cycles; MFMA-only cycles %.3e -> issue efficiency %.3f"
           % (np.median(ticks) / 100.0, np.median(cyc), need, need / np.median(cyc)))

@@ -38,6 +38,14 @@ int main(int argc, char **argv) {
     hipDeviceSynchronize();
     hipMemcpy(V2.data(), dV, M * 8, hipMemcpyDeviceToHost);
   }
+  std::vector<double> VT(M, 0.0);
+  if (Npad % 256 == 0) {
+    auto kern = w4::tall::post_kernel_w4t;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, w4::tall::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), w4::tall::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    hipDeviceSynchronize();
+    hipMemcpy(VT.data(), dV, M * 8, hipMemcpyDeviceToHost);
+  }
   {
     using GP = GemmF64<128, 256, 16, 2, 4, false, 1>;
     auto kern = w8::post_kernel<128, 256, 2, 4, 2, 1, true, true>;
@@ -49,7 +57,7 @@ int main(int argc, char **argv) {
   // host model: per candidate c, rows n: v = ascending fma chain over k; squares folded in the kernels' order:
   // lane group g = 0..3 holds rows 16 I + g + 4 r; per 128-row tile and half h: s = sum_{I in half} sum_r v^2 (fma chain),
   // colss[h] += s; then (g0 + g1) + (g2 + g3) per half, then half0 + half1
-  int bad4 = 0, bad2 = 0, bad8 = 0;
+  int bad4 = 0, bad2 = 0, bad8 = 0, badt = 0;
   for (int c = 0; c < M; ++c) {
     double colss[2][4] = {};
     for (int t = 0; t < Npad / 128; ++t)
@@ -75,6 +83,7 @@ int main(int argc, char **argv) {
     bad4 += memcmp(&ss, &V4[c], 8) != 0;
     bad2 += memcmp(&ss, &V2[c], 8) != 0;
     bad8 += memcmp(&ss, &V8[c], 8) != 0;
+    badt += Npad % 256 == 0 && memcmp(&ss, &VT[c], 8) != 0;
   }
-  printf("Npad %d, rows [%d, %d) nonzero: of %d candidates, differing from the host model: w4<4> %d, w4<2> %d, w8 %d\n", Npad, row_lo, nnz, M, bad4, bad2, bad8);
+  printf("Npad %d, rows [%d, %d) nonzero: of %d candidates, differing from the host model: w4<4> %d, w4<2> %d, w8 %d, tall %d\n", Npad, row_lo, nnz, M, bad4, bad2, bad8, badt);
 }
