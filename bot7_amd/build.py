@@ -58,7 +58,7 @@ def check_agpr_discipline():
     import re
     text = open(posterior_isa()).read()
     found = {}
-    for m in re.finditer(r"^(_ZN\S*post_kernel_w4(?:ILi(\d)E|t)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M):
+    for m in re.finditer(r"^(_ZN\S*post_kernel_w4(?:ILi(\d)E|tILi\d+ELi\d+E)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M):
         nj = int(m.group(2)) if m.group(2) else 16   # 16: the tall shape (16 strips of rows x 2 of candidates: 32 tiles)
         ntiles = 32 if nj == 16 else 8 * nj
         in_asm, stats, bad = False, {"mfma": 0, "mfma_from_zero": 0, "acc_reads": 0, "scratch": 0}, []

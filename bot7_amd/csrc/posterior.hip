@@ -181,12 +181,13 @@ __device__ __forceinline__ void stage(Frags<NJ> &f0, Frags<NJ> &f1, Stage<NJ> &g
   const double *qa = pa + ((int64_t)ld.t * BM) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
   ld.advance();
   // ---- first half: k-steps 0, 1 from F0
+  constexpr int K1 = (NS + NM - 1) / NM + 1, K2 = (NP + NM - 1) / NM + 1;  // side operations behind one MFMA, at most
   static_for<NM>([&](auto m_) {
     constexpr int m = decltype(m_)::value, ks = m / (NJ * NI), i = FIRST + (m % (NJ * NI)) / NJ, j = m % NJ;
     mfma_tile<NJ, i, j, ZERO && ks == 0>(f0.a[ks][i], f0.b[ks][j]);
-    static_for<NS>([&](auto s_) {
-      constexpr int sidx = decltype(s_)::value;
-      if constexpr (sidx >= m * NS / NM && sidx < (m + 1) * NS / NM) {
+    static_for<K1>([&](auto k_) {
+      constexpr int sidx = m * NS / NM + decltype(k_)::value;
+      if constexpr (sidx < (m + 1) * NS / NM) {
         if constexpr (sidx < NP) {
           if constexpr (sidx < NJ || sidx - NJ >= FIRST) read_pair<NJ, sidx, 2>(f1, cur + fa, cur + fb);
         } else if constexpr (sidx < NP + NC) {
@@ -203,9 +204,9 @@ __device__ __forceinline__ void stage(Frags<NJ> &f0, Frags<NJ> &f1, Stage<NJ> &g
   static_for<NM>([&](auto m_) {
     constexpr int m = decltype(m_)::value, ks = m / (NJ * NI), i = FIRST + (m % (NJ * NI)) / NJ, j = m % NJ;
     mfma_tile<NJ, i, j, false>(f1.a[ks][i], f1.b[ks][j]);
-    static_for<NP>([&](auto s_) {
-      constexpr int sidx = decltype(s_)::value;
-      if constexpr (sidx >= m * NP / NM && sidx < (m + 1) * NP / NM) read_pair<NJ, sidx, 0>(f0, nxt + fa, nxt + fb);
+    static_for<K2>([&](auto k_) {
+      constexpr int sidx = m * NP / NM + decltype(k_)::value;
+      if constexpr (sidx < (m + 1) * NP / NM) read_pair<NJ, sidx, 0>(f0, nxt + fa, nxt + fb);
     });
   });
 }
@@ -327,108 +328,116 @@ constexpr int lds_bytes() { return 2 * (BM + 64 * NJ) * LD * 8; }
 //   barrier
 //   k-step 3: MFMAs(set 1) | read set 0 = k-step 0 of the next stage
 // The fold runs over the two 128-row halves of the tile in the order of the 128-row kernels, so the bits are the same.
-namespace tall {
-constexpr int NJ = 2, NR = 16, BMT = 16 * NR, BN = 64 * NJ, A_DBLT = BMT * LD, STAGE_DBL = (BMT + BN) * LD;
-constexpr int NCA = BMT / 32, NC = NCA + 2 * NJ, NP = NR + NJ;
-constexpr int LDS_BYTES = 2 * STAGE_DBL * 8;
+template <int NJ, int NR>
+struct Tall {
+  static constexpr int BMT = 16 * NR, BN = 64 * NJ, A_DBLT = BMT * LD, STAGE_DBL = (BMT + BN) * LD;
+  static constexpr int NCA = BMT / 32, NC = NCA + 2 * NJ, NP = NR + NJ;
+  static constexpr int LDS_BYTES = 2 * STAGE_DBL * 8;
+  static_assert(NJ * NR == 32, "32 accumulator tiles per wave");
 
-struct Set {
-  double a[NR], b[NJ];
-};
-struct Data {
-  d2_t c[NC];
-};
-struct Cursor {
-  int t, kb, ntiles;
-  __device__ __forceinline__ void advance() {
-    if (kb + 1 < (t + 1) * (BMT / BK)) {
-      ++kb;
-    } else if (t + 1 < ntiles) {
-      ++t;
-      kb = 0;
+  struct Set {
+    double a[NR], b[NJ];
+  };
+  struct Data {
+    d2_t c[NC];
+  };
+  struct Cursor {
+    int t, kb, ntiles;
+    __device__ __forceinline__ void advance() {
+      if (kb + 1 < (t + 1) * (BMT / BK)) {
+        ++kb;
+      } else if (t + 1 < ntiles) {
+        ++t;
+        kb = 0;
+      }
     }
+  };
+
+  // fragment P of k-step S: P < NJ candidates strip P, else rows strip P - NJ
+  template <int P, int S>
+  static __device__ __forceinline__ void read_one(Set &f, const double *__restrict__ sa, const double *__restrict__ sb) {
+    if constexpr (P < NJ)
+      f.b[P] = sb[P * 16 * LD + 4 * S];
+    else
+      f.a[P - NJ] = sa[(P - NJ) * 16 * LD + 4 * S];
+  }
+  template <int C>
+  static __device__ __forceinline__ void load_chunk(Data &g, const double *__restrict__ qa, const double *__restrict__ qb,
+                                                    int64_t lda) {
+    if constexpr (C < NCA)
+      g.c[C] = *reinterpret_cast<const d2_t *>(qa + (int64_t)(32 * C) * lda);
+    else
+      g.c[C] = *reinterpret_cast<const d2_t *>(qb + (int64_t)(32 * (C - NCA)) * lda);
+  }
+  template <int C>
+  static __device__ __forceinline__ void store_chunk(const Data &g, double *__restrict__ w) {
+    constexpr int o = C < NCA ? 32 * C * LD : A_DBLT + 32 * (C - NCA) * LD;
+    w[o] = g.c[C][0];
+    w[o + 1] = g.c[C][1];
+  }
+
+  // one k-step: NJ * (NR - FIRST) MFMAs from set `use`, NSIDE side operations spread between them
+  template <int FIRST, bool ZERO, int NSIDE, class Side>
+  static __device__ __forceinline__ void kstep(const Set &use, Side &&side) {
+    constexpr int NI = NR - FIRST, NM = NJ * NI;
+    constexpr int KMAX = (NSIDE + NM - 1) / NM + 1;  // side operations behind one MFMA: [m NSIDE / NM, (m + 1) NSIDE / NM)
+    static_for<NM>([&](auto m_) {
+      constexpr int m = decltype(m_)::value, i = FIRST + m / NJ, j = m % NJ;
+      mfma_tile<NJ, i, j, ZERO>(use.a[i], use.b[j]);
+      static_for<KMAX>([&](auto k_) {
+        constexpr int sidx = m * NSIDE / NM + decltype(k_)::value;
+        if constexpr (sidx < (m + 1) * NSIDE / NM) side(std::integral_constant<int, sidx>{});
+      });
+    });
+  }
+
+  // FIRST / NEXT_FIRST: first strip with anything to do in this stage / in the next one
+  template <int FIRST, int NEXT_FIRST, bool ZERO>
+  static __device__ __forceinline__ void stage(Set &s0, Set &s1, Data &g, double *__restrict__ cur, double *__restrict__ nxt,
+                                               int fa, int fb, int wofs, const double *__restrict__ pa,
+                                               const double *__restrict__ pb, int64_t lda, Cursor &ld) {
+    constexpr int H = NC / 2;
+    const double *qa = pa + ((int64_t)ld.t * BMT) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
+    ld.advance();
+    kstep<FIRST, ZERO, NP + H>(s0, [&](auto s_) {
+      constexpr int x = decltype(s_)::value;
+      if constexpr (x < NP) {
+        if constexpr (x < NJ || x - NJ >= FIRST) read_one<x, 1>(s1, cur + fa, cur + fb);
+      } else {
+        store_chunk<x - NP>(g, nxt + wofs);
+      }
+    });
+    kstep<FIRST, false, NP + NC - H>(s1, [&](auto s_) {
+      constexpr int x = decltype(s_)::value;
+      if constexpr (x < NP) {
+        if constexpr (x < NJ || x - NJ >= FIRST) read_one<x, 2>(s0, cur + fa, cur + fb);
+      } else {
+        store_chunk<H + x - NP>(g, nxt + wofs);
+      }
+    });
+    kstep<FIRST, false, NP + NC>(s0, [&](auto s_) {
+      constexpr int x = decltype(s_)::value;
+      if constexpr (x < NP) {
+        if constexpr (x < NJ || x - NJ >= FIRST) read_one<x, 3>(s1, cur + fa, cur + fb);
+      } else {
+        load_chunk<x - NP>(g, qa, qb, lda);
+      }
+    });
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's part of the next image is in LDS (the loads stay in flight)
+    __builtin_amdgcn_s_barrier();
+    kstep<FIRST, false, NP>(s1, [&](auto s_) {
+      constexpr int x = decltype(s_)::value;
+      if constexpr (x < NJ || x - NJ >= NEXT_FIRST) read_one<x, 0>(s0, nxt + fa, nxt + fb);
+    });
   }
 };
 
-// fragment P of k-step S: P < NJ candidates strip P, else rows strip P - NJ
-template <int P, int S>
-__device__ __forceinline__ void read_one(Set &f, const double *__restrict__ sa, const double *__restrict__ sb) {
-  if constexpr (P < NJ)
-    f.b[P] = sb[P * 16 * LD + 4 * S];
-  else
-    f.a[P - NJ] = sa[(P - NJ) * 16 * LD + 4 * S];
-}
-template <int C>
-__device__ __forceinline__ void load_chunk(Data &g, const double *__restrict__ qa, const double *__restrict__ qb, int64_t lda) {
-  if constexpr (C < NCA)
-    g.c[C] = *reinterpret_cast<const d2_t *>(qa + (int64_t)(32 * C) * lda);
-  else
-    g.c[C] = *reinterpret_cast<const d2_t *>(qb + (int64_t)(32 * (C - NCA)) * lda);
-}
-template <int C>
-__device__ __forceinline__ void store_chunk(const Data &g, double *__restrict__ w) {
-  constexpr int o = C < NCA ? 32 * C * LD : A_DBLT + 32 * (C - NCA) * LD;
-  w[o] = g.c[C][0];
-  w[o + 1] = g.c[C][1];
-}
-
-// one k-step: NJ * (NR - FIRST) MFMAs from set `use`, NSIDE side operations spread between them
-template <int FIRST, bool ZERO, int NSIDE, class Side>
-__device__ __forceinline__ void kstep(const Set &use, Side &&side) {
-  constexpr int NI = NR - FIRST, NM = NJ * NI;
-  static_for<NM>([&](auto m_) {
-    constexpr int m = decltype(m_)::value, i = FIRST + m / NJ, j = m % NJ;
-    mfma_tile<NJ, i, j, ZERO>(use.a[i], use.b[j]);
-    static_for<NSIDE>([&](auto s_) {
-      constexpr int sidx = decltype(s_)::value;
-      if constexpr (sidx >= m * NSIDE / NM && sidx < (m + 1) * NSIDE / NM) side(s_);
-    });
-  });
-}
-
-// FIRST / NEXT_FIRST: first strip with anything to do in this stage / in the next one
-template <int FIRST, int NEXT_FIRST, bool ZERO>
-__device__ __forceinline__ void stage(Set &s0, Set &s1, Data &g, double *__restrict__ cur, double *__restrict__ nxt, int fa,
-                                      int fb, int wofs, const double *__restrict__ pa, const double *__restrict__ pb,
-                                      int64_t lda, Cursor &ld) {
-  constexpr int H = NC / 2;
-  const double *qa = pa + ((int64_t)ld.t * BMT) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
-  ld.advance();
-  kstep<FIRST, ZERO, NP + H>(s0, [&](auto s_) {
-    constexpr int x = decltype(s_)::value;
-    if constexpr (x < NP) {
-      if constexpr (x < NJ || x - NJ >= FIRST) read_one<x, 1>(s1, cur + fa, cur + fb);
-    } else {
-      store_chunk<x - NP>(g, nxt + wofs);
-    }
-  });
-  kstep<FIRST, false, NP + NC - H>(s1, [&](auto s_) {
-    constexpr int x = decltype(s_)::value;
-    if constexpr (x < NP) {
-      if constexpr (x < NJ || x - NJ >= FIRST) read_one<x, 2>(s0, cur + fa, cur + fb);
-    } else {
-      store_chunk<H + x - NP>(g, nxt + wofs);
-    }
-  });
-  kstep<FIRST, false, NP + NC>(s0, [&](auto s_) {
-    constexpr int x = decltype(s_)::value;
-    if constexpr (x < NP) {
-      if constexpr (x < NJ || x - NJ >= FIRST) read_one<x, 3>(s1, cur + fa, cur + fb);
-    } else {
-      load_chunk<x - NP>(g, qa, qb, lda);
-    }
-  });
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's part of the next image is in LDS (the loads stay in flight)
-  __builtin_amdgcn_s_barrier();
-  kstep<FIRST, false, NP>(s1, [&](auto s_) {
-    constexpr int x = decltype(s_)::value;
-    if constexpr (x < NJ || x - NJ >= NEXT_FIRST) read_one<x, 0>(s0, nxt + fa, nxt + fb);
-  });
-}
-
+template <int NJ, int NR>
 __global__ void __launch_bounds__(256)
     post_kernel_w4t(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0, int64_t Mtotal,
                     double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var) {
+  using T = Tall<NJ, NR>;
+  constexpr int BMT = T::BMT, BN = T::BN, NC = T::NC, NP = T::NP;
   extern __shared__ __align__(16) double sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef B7_POST_STAMPS
@@ -441,57 +450,49 @@ __global__ void __launch_bounds__(256)
   const double *pb = ks + ((int64_t)blockIdx.x * BN + r0) * lda + 2 * kc;
   const int wofs = r0 * LD + 2 * kc;
   const int fa = (lane & 15) * LD + (lane >> 4);
-  const int fb = A_DBLT + (wave * 16 * NJ + (lane & 15)) * LD + (lane >> 4);
+  const int fb = T::A_DBLT + (wave * 16 * NJ + (lane & 15)) * LD + (lane >> 4);
 
   const int ntiles = Npad / BMT;
-  Cursor ld{0, 0, ntiles};
-  Data g;
-  Set s0, s1;
-  double *const b0 = sm, *const b1 = sm + STAGE_DBL;
-  static_for<NC>([&](auto c_) { load_chunk<decltype(c_)::value>(g, pa, pb, lda); });  // stage 0
+  typename T::Cursor ld{0, 0, ntiles};
+  typename T::Data g;
+  typename T::Set s0, s1;
+  double *const b0 = sm, *const b1 = sm + T::STAGE_DBL;
+  static_for<NC>([&](auto c_) { T::template load_chunk<decltype(c_)::value>(g, pa, pb, lda); });  // stage 0
   ld.advance();
-  static_for<NC>([&](auto c_) { store_chunk<decltype(c_)::value>(g, b0 + wofs); });
+  static_for<NC>([&](auto c_) { T::template store_chunk<decltype(c_)::value>(g, b0 + wofs); });
   {
     const double *qa = pa + ((int64_t)ld.t * BMT) * lda + ld.kb * BK, *qb = pb + ld.kb * BK;
-    static_for<NC>([&](auto c_) { load_chunk<decltype(c_)::value>(g, qa, qb, lda); });  // stage 1: stored during stage 0
+    static_for<NC>([&](auto c_) { T::template load_chunk<decltype(c_)::value>(g, qa, qb, lda); });  // stage 1
     ld.advance();
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
-  static_for<NP>([&](auto p_) { read_one<decltype(p_)::value, 0>(s0, b0 + fa, b0 + fb); });
+  static_for<NP>([&](auto p_) { T::template read_one<decltype(p_)::value, 0>(s0, b0 + fa, b0 + fb); });
 
   double colss[2][NJ] = {};
-#define B7_STAGE(F, NF, Z, CUR, NXT) stage<F, NF, Z>(s0, s1, g, CUR, NXT, fa, fb, wofs, pa, pb, lda, ld)
+#define B7_STAGE(F, NF, Z, CUR, NXT) T::template stage<F, NF, Z>(s0, s1, g, CUR, NXT, fa, fb, wofs, pa, pb, lda, ld)
   for (int t = 0; t < ntiles; ++t) {
     B7_STAGE(0, 0, true, b0, b1);
     if (t > 0) {
-      for (int p = 0; p < 8 * t - 1; ++p) {
+      for (int p = 0; p < (NR / 2) * t - 1; ++p) {
         B7_STAGE(0, 0, false, b1, b0);
         B7_STAGE(0, 0, false, b0, b1);
       }
       B7_STAGE(0, 0, false, b1, b0);
       B7_STAGE(0, 1, false, b0, b1);  // diagonal stage 0
     }
-    // diagonal stages 1..15 (for t == 0 the zeroing stage above was diagonal stage 0; it read the next set in full)
-    B7_STAGE(1, 2, false, b1, b0);
-    B7_STAGE(2, 3, false, b0, b1);
-    B7_STAGE(3, 4, false, b1, b0);
-    B7_STAGE(4, 5, false, b0, b1);
-    B7_STAGE(5, 6, false, b1, b0);
-    B7_STAGE(6, 7, false, b0, b1);
-    B7_STAGE(7, 8, false, b1, b0);
-    B7_STAGE(8, 9, false, b0, b1);
-    B7_STAGE(9, 10, false, b1, b0);
-    B7_STAGE(10, 11, false, b0, b1);
-    B7_STAGE(11, 12, false, b1, b0);
-    B7_STAGE(12, 13, false, b0, b1);
-    B7_STAGE(13, 14, false, b1, b0);
-    B7_STAGE(14, 15, false, b0, b1);
-    B7_STAGE(15, 0, false, b1, b0);
+    // diagonal stages 1 .. NR-1 (for t == 0 the zeroing stage above was diagonal stage 0; it read the next set in full)
+    static_for<NR - 1>([&](auto q_) {
+      constexpr int Q = decltype(q_)::value + 1;
+      if constexpr (Q % 2 == 1)
+        B7_STAGE(Q, (Q + 1) % NR, false, b1, b0);
+      else
+        B7_STAGE(Q, (Q + 1) % NR, false, b0, b1);
+    });
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    // the 256-row tile is two 128-row tiles of the fold: (rows 0..63, 64..127) of the first, then of the second
-    static_for<4 * NJ>([&](auto qj_) {
-      constexpr int q = decltype(qj_)::value / NJ, j = decltype(qj_)::value % NJ;  // q: quarter of the tile
+    // the tile is NR/8 128-row tiles of the fold, each as (rows 0..63, rows 64..127), in ascending order
+    static_for<(NR / 4) * NJ>([&](auto qj_) {
+      constexpr int q = decltype(qj_)::value / NJ, j = decltype(qj_)::value % NJ;  // q: 64-row group of the tile
       double s = 0.0;
       static_for<4>([&](auto i_) {
         double v[4];
@@ -529,7 +530,6 @@ __global__ void __launch_bounds__(256)
   }
 #endif
 }
-}  // namespace tall
 }  // namespace w4
 
 #ifndef B7_POST_NO_LAUNCHERS
@@ -548,12 +548,14 @@ int launch_post_w4(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int6
 }
 }  // namespace
 
+template <int NJ, int NR>
 static int launch_post_tall(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
-  namespace T = w4::tall;
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(T::post_kernel_w4t), hipFuncAttributeMaxDynamicSharedMemorySize,
+  using T = w4::Tall<NJ, NR>;
+  auto kern = w4::post_kernel_w4t<NJ, NR>;
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));
   const bool blr = c->model_kind == 1;
-  hipLaunchKernelGGL(T::post_kernel_w4t, dim3((unsigned)(rows / T::BN)), dim3(256), T::LDS_BYTES, c->stream,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / T::BN)), dim3(256), T::LDS_BYTES, c->stream,
                      (const double *)c->Linv.p, ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
                      blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
   B7_HIP(c, hipGetLastError());
@@ -563,7 +565,7 @@ static int launch_post_tall(b7_ctx *c, const double *ks, int64_t row0, int64_t r
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
   PhaseScope ps(c, "post");
   // large grids: the tall shape (n-tiles of 256 rows: half the K* bytes through the L2) when the padded N allows it
-  if (c->Npad % 256 == 0 && rows / 256 >= c->cus) return launch_post_tall(c, ks, row0, rows, Mtotal, var);
+  if (c->Npad % 256 == 0 && rows / 256 >= c->cus) return launch_post_tall<2, 16>(c, ks, row0, rows, Mtotal, var);
   // 256 candidates per workgroup when that still gives every CU one; otherwise 128 (same arithmetic, same bits)
   if (rows / 256 < c->cus) return launch_post_w4<2>(c, ks, row0, rows, Mtotal, var);
   return launch_post_w4<4>(c, ks, row0, rows, Mtotal, var);

@@ -40,9 +40,10 @@ int main(int argc, char **argv) {
   }
   std::vector<double> VT(M, 0.0);
   if (Npad % 256 == 0) {
-    auto kern = w4::tall::post_kernel_w4t;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, w4::tall::LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), w4::tall::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    using T = w4::Tall<2, 16>;
+    auto kern = w4::post_kernel_w4t<2, 16>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(M / T::BN), dim3(256), T::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
     hipDeviceSynchronize();
     hipMemcpy(VT.data(), dV, M * 8, hipMemcpyDeviceToHost);
   }
