@@ -410,6 +410,51 @@ def test_posterior_kernels_reproduce_the_host_model_bit_for_bit():
         assert "differing from the host model: w4<4> 0, w4<2> 0, w8 0, tall 0" in out.stdout, out.stdout
 
 
+def test_posterior_and_ei_against_50_digit_arithmetic(ctx):
+    """The HIP path against textbook GP regression and closed-form EI evaluated in 50-digit arithmetic (mpmath), with no
+    oracle in between: posterior mean and variance of a small well-conditioned problem, the likelihood, and EI with the
+    reference's A&S erf replaced by the exact one (so EI agrees to the polynomial's 1.5e-7, utils/math.lua:261-288)."""
+    import mpmath
+    mpmath.mp.dps = 50
+    try:
+        rng = np.random.default_rng(11)
+        N, M, d = 24, 40, 3
+        X, Xs = rng.random((N, d)), rng.random((M, d))
+        Y = np.sin(3 * X.sum(1)).reshape(-1, 1)
+        ls, amp, noise, mean = np.array([0.4, 0.7, 0.3]), 1.3, 1e-3, 0.2
+        ctx.grid_upload(Xs)
+        rep = ctx.gp_fit(X, Y, ls, amp, noise, mean, want_nll=True)
+        mu, var = ctx.gp_predict()
+        ctx.score_reset()
+        ctx.score_ei([float(Y.min())], 0.0)
+        _, _, ei = ctx.score_finish(1.0, download=True)
+
+        def k(a, b):
+            return mpmath.mpf(amp) * mpmath.exp(-sum((mpmath.mpf(a[i]) - mpmath.mpf(b[i])) ** 2 / mpmath.mpf(ls[i])
+                                                     for i in range(d)) / 2)
+        K = mpmath.matrix(N, N)
+        for i in range(N):
+            for j in range(N):
+                K[i, j] = k(X[i], X[j]) + (mpmath.mpf(noise) if i == j else 0)
+        Ki = K ** -1
+        r = mpmath.matrix([mpmath.mpf(float(y)) - mean for y in Y[:, 0]])
+        nll = (r.T * Ki * r)[0] / 2 + mpmath.log(mpmath.det(K)) / 2 + N * mpmath.log(2 * mpmath.pi) / 2
+        assert float(abs(rep["nll"][0] - nll) / abs(nll)) < 1e-10
+        fmin = mpmath.mpf(float(Y.min()))
+        for j in range(M):
+            ks = mpmath.matrix([k(Xs[j], X[i]) for i in range(N)])
+            mu_j = mean + (ks.T * Ki * r)[0]
+            var_j = mpmath.mpf(amp) - (ks.T * Ki * ks)[0]
+            assert float(abs(mu[j, 0] - mu_j)) < 1e-9
+            assert float(abs(var[j] - var_j) / var_j) < 1e-8
+            sd = mpmath.sqrt(var_j)
+            z = (fmin - mu_j) / sd
+            ei_j = max(mpmath.mpf(0), (fmin - mu_j) * mpmath.ncdf(z) + sd * mpmath.npdf(z))
+            assert float(abs(ei[j] - ei_j)) < 4e-7 * max(1.0, float(abs(fmin - mu_j)))
+    finally:
+        mpmath.mp.dps = 15
+
+
 def _marg_hyps(hyp, S):
     hyps = []
     for s in range(S):
