@@ -1072,9 +1072,15 @@ static int upload_net(b7_ctx *c, const b7_mlp *net, int *z_out) {
     memcpy(&pack[off], net->b[l], (size_t)net->dims[l + 1] * sizeof(double));
     off += net->dims[l + 1];
   }
-  B7_TRY(b7_ensure(c, c->netbuf, total * sizeof(double)));
-  B7_HIP(c, hipMemcpy(c->netbuf.p, pack.data(), total * sizeof(double), hipMemcpyHostToDevice));
   *z_out = net->dims[net->n_layers];
+  // the same network as last time (models/dngo.lua:155-171 runs it over X_obs and then over the candidates): already there
+  if (c->net_host.size() == total && c->netbuf.cap >= total * sizeof(double) &&
+      memcmp(c->net_host.data(), pack.data(), total * sizeof(double)) == 0)
+    return B7_OK;
+  B7_TRY(b7_ensure(c, c->netbuf, total * sizeof(double)));
+  B7_HIP(c, hipStreamSynchronize(c->stream));  // nobody is reading the old weights any more
+  B7_HIP(c, hipMemcpy(c->netbuf.p, pack.data(), total * sizeof(double), hipMemcpyHostToDevice));
+  c->net_host.swap(pack);
   return B7_OK;
 }
 

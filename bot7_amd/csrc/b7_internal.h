@@ -90,6 +90,7 @@ struct b7_ctx {
   // staging: kernels write
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
+  std::vector<double> net_host;  // the basis network last uploaded to netbuf (packed W, b per layer)
   void *pin_eval = nullptr;  // b7_eval_nominate: [S][4] pivot reports + [S][d] lengthscale staging (pinned)
   size_t pin_eval_bytes = 0;
   void *pinned_dev = nullptr;
