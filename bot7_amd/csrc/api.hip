@@ -170,7 +170,8 @@ void b7_destroy(b7_ctx *c) {
   DevBuf *all[] = {&c->grid[0], &c->grid[1], &c->xobs, &c->w,     &c->zsc,  &c->zss,     &c->K,      &c->L,
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
                    &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pstamps,
-                   &c->bhyp, &c->bw, &c->bzsc, &c->bzss, &c->bK, &c->bL, &c->bdinv, &c->bflags, &c->binfo, &c->bresid, &c->bterms};
+                   &c->bhyp, &c->bw, &c->bzsc, &c->bzss, &c->bK, &c->bL, &c->bdinv, &c->bflags, &c->binfo, &c->bresid, &c->bterms,
+                   &c->bLinv, &c->balpha};
   for (auto &kv : c->pjobs_cache) b7_release(kv.second.buf);
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
@@ -709,8 +710,8 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
     const int64_t Mpad = round_up(c->M, B7_MROWS);
     B7_TRY(b7_ensure(c, c->ks, (size_t)(chunk > Mpad ? Mpad : chunk) * row_bytes));
   }
-  // lengthscales of all S samples: one pinned staging block, one upload
-  const size_t ls_bytes = sizeof(double) * (size_t)S * d, rep_bytes = 16 * (size_t)S;
+  // pinned staging: [S][4] pivot reports | hypers of all S samples ([S][d] lengthscales, then S amp, S noise, S mean)
+  const size_t hyp_doubles = (size_t)S * (d + 3), ls_bytes = sizeof(double) * hyp_doubles, rep_bytes = 16 * (size_t)S;
   if (c->pin_eval_bytes < ls_bytes + rep_bytes) {
     if (c->pin_eval) (void)hipHostFree(c->pin_eval);
     c->pin_eval = nullptr;
@@ -720,26 +721,85 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
   }
   B7_TRY(b7_ensure(c, c->bhyp, ls_bytes));
   int *reports = static_cast<int *>(c->pin_eval);                                        // [S][4]
-  double *ls_host = reinterpret_cast<double *>(static_cast<char *>(c->pin_eval) + rep_bytes);  // [S][d]
-  for (int s = 0; s < S; ++s) memcpy(ls_host + (size_t)s * d, hyps[s].lenscale_sq, sizeof(double) * d);
+  double *ls_host = reinterpret_cast<double *>(static_cast<char *>(c->pin_eval) + rep_bytes);  // [S][d] | amp | noise | mean
+  for (int s = 0; s < S; ++s) {
+    memcpy(ls_host + (size_t)s * d, hyps[s].lenscale_sq, sizeof(double) * d);
+    ls_host[(size_t)S * d + s] = hyps[s].amp;
+    ls_host[(size_t)S * (d + 1) + s] = hyps[s].noise;
+    ls_host[(size_t)S * (d + 2) + s] = hyps[s].mean;
+  }
   memset(reports, 0xff, rep_bytes);
+  // the fits of all samples side by side in one persistent launch (one critical workgroup each) when that schedule serves
+  // this size and the responses are a single column; otherwise one after the other
+  const bool batch = S > 1 && c->ycols == 1 && c->potrf_sched == 3 && c->Npad <= 2048 && c->inverse_inline;
+  const int n = c->Npad;
+  const size_t nn = (size_t)n * n;
+  if (batch) {
+    const size_t fw = persist_flag_words_host(n / B7_PANEL);
+    B7_TRY(b7_ensure(c, c->bw, sizeof(double) * (size_t)S * c->dpad));
+    B7_TRY(b7_ensure(c, c->bzsc, sizeof(double) * (size_t)S * n * c->dpad));
+    B7_TRY(b7_ensure(c, c->bzss, sizeof(double) * (size_t)S * n));
+    B7_TRY(b7_ensure(c, c->bK, sizeof(double) * S * nn));
+    B7_TRY(b7_ensure(c, c->bL, sizeof(double) * S * nn));
+    B7_TRY(b7_ensure(c, c->bLinv, sizeof(double) * S * nn));
+    B7_TRY(b7_ensure(c, c->bdinv, sizeof(double) * (size_t)S * n * B7_PANEL));
+    B7_TRY(b7_ensure(c, c->bflags, sizeof(unsigned) * S * fw));
+    B7_TRY(b7_ensure(c, c->binfo, sizeof(int) * 4 * (size_t)S));
+    B7_TRY(b7_ensure(c, c->bresid, sizeof(double) * (size_t)S * n));
+    B7_TRY(b7_ensure(c, c->balpha, sizeof(double) * (size_t)S * n));
+  }
   B7_HIP(c, hipMemcpyAsync(c->bhyp.p, ls_host, ls_bytes, hipMemcpyHostToDevice, c->stream));
   double *fd = nullptr;
   if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
 
   B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69
   c->acc_valid = true;
-  for (int s = 0; s < S; ++s) {
-    B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
-    B7_TRY(launch_potrf(c, 0.0, true));
-    if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
-    B7_TRY(launch_alpha(c));
-    B7_HIP(c, hipMemcpyAsync(reports + 4 * s, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
-    c->fitted = true;
-    B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
+  if (batch) {
+    const double *hyp_dev = (const double *)c->bhyp.p, *amp_dev = hyp_dev + (size_t)S * d, *noise_dev = amp_dev + S,
+                 *mean_dev = noise_dev + S;
+    hipLaunchKernelGGL(resid_batch_kernel, dim3((n + 255) / 256, S), dim3(256), 0, c->stream, (const double *)c->ybuf.p,
+                       (double *)c->bresid.p, c->N, n, mean_dev);
+    B7_TRY(launch_kxx_batch(c, S, hyp_dev, amp_dev, noise_dev, (double *)c->bw.p, (double *)c->bzsc.p, (double *)c->bzss.p,
+                            (double *)c->bK.p));
+    B7_TRY(launch_fit_batch(c, S, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bLinv.p, (double *)c->bdinv.p,
+                            (unsigned *)c->bflags.p, (int *)c->binfo.p));
+    B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p));
+    B7_HIP(c, hipMemcpyAsync(reports, c->binfo.p, rep_bytes, hipMemcpyDeviceToHost, c->stream));
+    // the posterior kernels read the fit through the context: point it at one sample's slot after the other
+    void *const zsc0 = c->zsc.p, *const zss0 = c->zss.p, *const w0 = c->w.p, *const alpha0 = c->alpha.p, *const linv0 = c->Linv.p;
+    int rc = B7_OK;
+    for (int s = 0; s < S && rc == B7_OK; ++s) {
+      c->zsc.p = (double *)c->bzsc.p + (size_t)s * n * c->dpad;
+      c->zss.p = (double *)c->bzss.p + (size_t)s * n;
+      c->w.p = (double *)c->bw.p + (size_t)s * c->dpad;
+      c->alpha.p = (double *)c->balpha.p + (size_t)s * n;
+      c->Linv.p = (double *)c->bLinv.p + s * nn;
+      c->amp = hyps[s].amp;
+      c->noise = hyps[s].noise;
+      c->mean = hyps[s].mean;
+      c->model_kind = 0;
+      c->fitted = true;
+      rc = predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p);
+      if (rc == B7_OK) rc = score_add(c, spec, fd);
+    }
+    c->zsc.p = zsc0, c->zss.p = zss0, c->w.p = w0, c->alpha.p = alpha0, c->Linv.p = linv0;
+    c->fitted = false;  // the context's own fit slot does not hold any of these fits
     c->predicted = true;
     c->Mpred = c->M;
-    B7_TRY(score_add(c, spec, fd));
+    B7_TRY(rc);
+  } else {
+    for (int s = 0; s < S; ++s) {
+      B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
+      B7_TRY(launch_potrf(c, 0.0, true));
+      if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
+      B7_TRY(launch_alpha(c));
+      B7_HIP(c, hipMemcpyAsync(reports + 4 * s, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
+      c->fitted = true;
+      B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
+      c->predicted = true;
+      c->Mpred = c->M;
+      B7_TRY(score_add(c, spec, fd));
+    }
   }
   // without a communicator the arg-max is enqueued before the host has seen any report; with one, the collective
   // must come after the check (a rank that redoes its nomination would otherwise issue one collective too many)

@@ -110,7 +110,7 @@ struct b7_ctx {
   DevBuf pstamps;  // diagnostics (B7_PERSIST_STAMPS)
   int pjobs_nb = 0, pjobs_n = 0;   // shape of the last single persistent launch (for the stamp reader)
   // b7_gp_nll_batch: B fits of the resident data in likelihood mode
-  DevBuf bhyp, bw, bzsc, bzss, bK, bL, bdinv, bflags, binfo, bresid, bterms;
+  DevBuf bhyp, bw, bzsc, bzss, bK, bL, bdinv, bflags, binfo, bresid, bterms, bLinv, balpha;
   bool persist_attr_set = false, persist_stamps = false;
   int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
@@ -215,6 +215,8 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
                    double *terms, double extra);
 size_t persist_flag_words_host(int nb);
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
+int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha);  // B single-column fits
+int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, unsigned *flags, int *info);
 int launch_nll_terms(b7_ctx *c, double *out_dev);  // out[0] = sum log L_ii, out[1 + k] = r_k' alpha_k
 int launch_fro_norm_sq(b7_ctx *c, const double *A, int n, int ld, double *out_dev);  // sum of squares of A[0:n, 0:n]
 int launch_set_identity(b7_ctx *c);    // L = I (Npad x Npad), dinv = identity blocks: the chol(I) fallback

@@ -447,9 +447,12 @@ __global__ void __launch_bounds__(256)
 // t = Linv * r  (lower triangular matrix-vector, one wave per row, ycols right-hand sides)
 __global__ void __launch_bounds__(256)
     trmv_lower_kernel(const double *__restrict__ Linv, const double *__restrict__ r, double *__restrict__ t, int n,
-                      int ycols) {
+                      int ycols, int64_t sLinv = 0, int64_t sr = 0, int64_t st = 0) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n) return;
+  Linv += blockIdx.z * sLinv;  // a batch of independent systems: grid.z = fit
+  r += blockIdx.z * sr;
+  t += blockIdx.z * st;
   for (int cidx = 0; cidx < ycols; ++cidx) {
     double s = 0.0;
     // eight loads of each operand in flight per lane; the sum runs in the same order as the plain loop (same bits)
@@ -490,8 +493,11 @@ __global__ void __launch_bounds__(256)
 constexpr int TSL = 256;
 __global__ void __launch_bounds__(256)
     trmv_lower_t_part_kernel(const double *__restrict__ Linv, const double *__restrict__ t,
-                             double *__restrict__ part, int n, int ycols) {
+                             double *__restrict__ part, int n, int ycols, int64_t sLinv = 0, int64_t st = 0) {
   __shared__ double red[4][64];
+  Linv += blockIdx.z * sLinv;
+  t += blockIdx.z * st;
+  part += blockIdx.z * st;  // t and its slice partials share one block per fit: [n ycols | nslices ycols n]
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
   const int r0 = blockIdx.y * TSL + wave * 64;
   for (int cidx = 0; cidx < ycols; ++cidx) {
@@ -518,9 +524,11 @@ __global__ void __launch_bounds__(256)
 }
 __global__ void __launch_bounds__(256)
     trmv_lower_t_sum_kernel(const double *__restrict__ part, double *__restrict__ alpha, int n, int nreal, int ycols,
-                            int yld, int nslices) {
+                            int yld, int nslices, int64_t st = 0, int64_t salpha = 0) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= n) return;
+  part += blockIdx.z * st;
+  alpha += blockIdx.z * salpha;
   for (int cidx = 0; cidx < ycols; ++cidx) {
     double s = 0.0;
     for (int ib = col / TSL; ib < nslices; ++ib) s += part[((int64_t)ib * ycols + cidx) * n + col];
@@ -783,6 +791,23 @@ int launch_alpha(b7_ctx *c) {
                      (const double *)c->Linv.p, (const double *)t, part, n, c->ycols);
   hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double *)part,
                      (double *)c->alpha.p, n, c->N, c->ycols, c->yld, nslices);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+// alpha_b = Linv_b' (Linv_b r_b) for B single-column fits at once (grid.z = fit); the same kernels, the same sums
+int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha) {
+  const int n = c->Npad;
+  const int nslices = (n + TSL - 1) / TSL;
+  const int64_t st = (int64_t)n * (1 + nslices), nn = (int64_t)n * n;
+  B7_TRY(b7_ensure(c, c->atmp, sizeof(double) * (size_t)st * B));
+  PhaseScope ps(c, "alpha");
+  double *t = (double *)c->atmp.p;
+  hipLaunchKernelGGL(trmv_lower_kernel, dim3(n / 4, 1, B), dim3(256), 0, c->stream, Linv, resid, t, n, 1, nn, (int64_t)n, st);
+  hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices, B), dim3(256), 0, c->stream, Linv, (const double *)t,
+                     t + n, n, 1, nn, st);
+  hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256, 1, B), dim3(256), 0, c->stream, (const double *)(t + n),
+                     alpha, n, c->N, 1, 1, nslices, st, (int64_t)n);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

@@ -69,7 +69,7 @@ struct PArgs {
   int njobs, n, nb, nreal, with_inverse;
   double extra;
   // a batch of independent factorisations in one launch (blockIdx.y = fit): strides per fit, 0 for a single one
-  int64_t sK, sL, sdinv;
+  int64_t sK, sL, sdinv, sLinv;
   int sflags, sinfo;
   // likelihood mode (b7_gp_nll_batch): no inverse; one JOB_VEC per fit solves L z = r alongside and leaves
   // terms[0] = |z|^2, terms[1] = sum log L_ii
@@ -723,6 +723,7 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
     a.K += b * a.sK;
     a.L += b * a.sL;
     a.dinv += b * a.sdinv;
+    if (a.Linv) a.Linv += b * a.sLinv;
     a.flags += b * a.sflags;
     a.info += b * a.sinfo;
     if (a.resid) {
@@ -920,6 +921,47 @@ int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv,
     a.resid = resid + (int64_t)b0 * n;
     a.terms = terms + 2 * b0;
     B7_TRY(persist_launch(c, a, nb_here, 2, helpers));
+  }
+  return B7_OK;
+}
+
+// B complete fits (Cholesky + inverse) of B matrices in as few persistent launches as the chip holds: the hyper samples of one
+// nomination (b7_eval_nominate).  Every fit gets its own critical workgroup and an equal share of helpers; with B fits
+// side by side the helpers of one fit are few, but a single fit leaves most of them idle anyway (its dependent chain is what
+// takes the time), so B fits cost little more than one.  Same arithmetic per tile as the single launch, whatever the helper count.
+int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, unsigned *flags, int *info) {
+  PhaseScope ps(c, "potrf");
+  const int n = c->Npad, nb = n / NB;
+  const int4 *jobs = nullptr;
+  int njobs = 0;
+  B7_TRY(persist_jobs(c, nb, 1, &jobs, &njobs));
+  const int64_t nn = (int64_t)n * n;
+  const int fw = (int)persist_flag_words(nb);
+  const int max_per_launch = c->cus / 4 > 0 ? c->cus / 4 : 1;  // at least three helpers per fit
+  for (int b0 = 0; b0 < B;) {
+    const int left = B - b0, nb_here = left < max_per_launch ? left : max_per_launch;
+    int helpers = c->cus / nb_here - 1;
+    if (helpers > njobs) helpers = njobs;
+    PArgs a = {};
+    a.fault_panel = c->persist_fault;
+    a.K = K + b0 * nn;
+    a.L = L + b0 * nn;
+    a.Linv = Linv + b0 * nn;
+    a.dinv = dinv + (int64_t)b0 * n * NB;
+    a.flags = flags + (int64_t)b0 * fw;
+    a.info = info + b0 * 4;
+    a.n = n;
+    a.nb = nb;
+    a.nreal = c->N;
+    a.extra = 0.0;
+    a.sK = nn;
+    a.sL = nn;
+    a.sLinv = nn;
+    a.sdinv = (int64_t)n * NB;
+    a.sflags = fw;
+    a.sinfo = 4;
+    B7_TRY(persist_launch(c, a, nb_here, 1, helpers));
+    b0 += nb_here;
   }
   return B7_OK;
 }

@@ -268,8 +268,11 @@ int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offse
  * b7_score_finish_global(S, offset), bit for bit, but all S fits, posteriors and score:adds are enqueued back to
  * back and the host synchronises once: each fit's pivot report is checked afterwards, and a failed pivot (or a
  * hand-off time-out) redoes the nomination through the per-sample path with utils/math.lua:159-218's jitter
- * schedule.  jitter_out / info_out: nullable, S entries (as b7_gp_fit's).  The accumulator holds score / S
- * afterwards (b7_score_finish with divisor 1 downloads it). */
+ * schedule.  With S > 1 and one response column the S fits run SIDE BY SIDE in one persistent launch (one critical
+ * workgroup each): a fit's dependent chain leaves most of the chip idle, so ten fits cost little more than one.
+ * jitter_out / info_out: nullable, S entries (as b7_gp_fit's).  The accumulator holds score / S afterwards
+ * (b7_score_finish with divisor 1 downloads it); the context's own fit slot holds none of the S fits (fit again
+ * before b7_gp_predict). */
 #define B7_SCORE_EI 1 /* scores/expected_improvement.lua: needs fmin[ycols]; tradeoff = xi */
 #define B7_SCORE_CB 2 /* scores/confidence_bound.lua: tradeoff = kappa, upper, sign as b7_score_cb */
 typedef struct {

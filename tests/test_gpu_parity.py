@@ -490,6 +490,23 @@ def test_eval_nominate_is_the_per_sample_loop_in_one_call(ctx, orc, kind, d, N, 
     assert ctx.eval_nominate(hyps, global_row_offset=1000, **kw) == (val0, idx0 + 1000)
 
 
+def test_eval_nominate_more_hyper_samples_than_fit_side_by_side(ctx, orc):
+    """S = 70 hyper samples: the fits run side by side in persistent launches of at most CUs/4 = 64 fits (one critical
+    workgroup and three or more helpers each), so this takes two launches; same bits as seventy separate fits."""
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 3, 100, 700, lambda X: np.sin(2.0 * X).sum(axis=1, keepdims=True))
+    hyps = [dict(hyp, lenscale_sq=hyp["lenscale_sq"] * (0.7 + 0.01 * s), amp=hyp["amp"] * (1.0 + 0.003 * s)) for s in range(70)]
+    ctx.grid_upload(X_hid)
+    val0, idx0, scores0 = _hip_nominate(ctx, X_obs, Y, hyps, "ei")
+    ctx.gp_set_data(X_obs, Y)
+    val1, idx1 = ctx.eval_nominate(hyps, score="ei", fmin=[float(Y.min())])
+    _, _, scores1 = ctx.score_finish(1.0, download=True)
+    assert (val1, idx1) == (val0, idx0) and np.array_equal(scores1, scores0)
+    # the context's own fit slot holds none of the batch's fits: a posterior needs a new fit
+    import bot7_amd
+    with pytest.raises(bot7_amd.Bot7HipError):
+        ctx.gp_predict()
+
+
 def test_eval_nominate_with_fantasy_columns(ctx, orc):
     """c > 1 response columns (the fantasies of scores/expected_improvement.lua:51-60): EI is the row mean over the
     columns (:83-85); one call against the separate entry points and against the oracle."""
