@@ -631,7 +631,9 @@ int b7_gp_predict_hyp(b7_ctx *c, const b7_hyp *hyp, double *mean_host, double *v
 // (the pivot report) plus one for the arg-max; at small N and M (cfg2: 0.2 ms of GPU work per sample) the round trips
 // are a third of the wall time.  Here every sample's fit, posterior and score:add are enqueued back to back, each
 // fit's 16-byte pivot report is copied into its own pinned slot in stream order, the arg-max follows, and the host
-// synchronises ONCE.  A report that says "pivot failed" or "hand-off timed out" (rare) throws the accumulated score
+// synchronises ONCE.  Knowing all S samples up front also lets the S fits run SIDE BY SIDE: one persistent launch with
+// grid.y = sample (launch_fit_batch), K assembly, residuals and alpha batched the same way; a fit is a dependent chain
+// that leaves most of the chip idle, so ten cost little more than one (cfg2, S = 10: 1.55 -> 0.75 ms per nomination).  A report that says "pivot failed" or "hand-off timed out" (rare) throws the accumulated score
 // away and redoes the whole nomination through the per-sample path, jitter schedule included, so the result is the
 // one the separate calls give.
 static int stage_fmin(b7_ctx *c, const double *fmin, double **fd_out) {
