@@ -885,9 +885,20 @@ int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
   return B7_OK;
 }
 
-// B likelihood evaluations of the resident data set under B hyper vectors (b7_gp_nll_batch): per fit the factorisation and
-// L z = r in likelihood mode, as many fits per launch as fit on the chip, launches back to back.
-// K: B x n x n assembled matrices; L, dinv, flags, info: scratch per fit; resid: B x n; terms: B x 2.
+// How many fits to run side by side in one persistent launch.  A fit takes max(its dependent chain, its trailing work / its
+// helpers), the chain grows with the number of panels nb and the work with nb^3, so the helpers a fit needs to stay on its
+// chain grow with nb.  Swept on MI355X (16 fits, all in one launch vs 8 / 4 / 2 / 1 per launch): with the inverse nb helpers
+// per fit are plenty (N = 2048: 8 fits per launch 3.24 ms, 16: 3.38, 4: 3.57; N = 1024: 16 per launch 0.50 ms, 8: 0.61),
+// without it nb / 2 (N = 2048, 16 likelihoods: 2.11 ms in one launch, 2.51 in two); never fewer than three.  The rule
+// below asks for a little less so that the common batch sizes (10, 16) are not split 15 + 1; batches that do not fit are
+// cut into equal launches.
+static int fits_per_launch(const b7_ctx *c, int nb, bool with_inverse) {
+  int h = with_inverse ? 3 * nb / 4 : nb / 2 - 1;
+  if (h < 3) h = 3;
+  const int p = c->cus / (1 + h);
+  return p < 1 ? 1 : p;
+}
+
 int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv, unsigned *flags, int *info,
                      const double *resid, double *terms, const double *extra_per_fit_unused) {
   (void)extra_per_fit_unused;
@@ -896,12 +907,15 @@ int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv,
   const int4 *jobs = nullptr;
   int njobs = 0;
   B7_TRY(persist_jobs(c, nb, 2, &jobs, &njobs));
-  const int helpers = njobs < c->cus - 1 ? njobs : c->cus - 1;
-  const int per_launch = c->cus / (1 + helpers) > 0 ? c->cus / (1 + helpers) : 1;
   const int64_t nn = (int64_t)n * n;
   const int fw = (int)persist_flag_words(nb);
-  for (int b0 = 0; b0 < B; b0 += per_launch) {
-    const int nb_here = B - b0 < per_launch ? B - b0 : per_launch;
+  // fits side by side per launch (fits_per_launch): sixteen likelihoods at N = 1024 are one launch, not sixteen
+  const int max_per_launch = fits_per_launch(c, nb, false);
+  const int nlaunch = (B + max_per_launch - 1) / max_per_launch, even = (B + nlaunch - 1) / nlaunch;
+  for (int b0 = 0, nb_here = 0; b0 < B; b0 += nb_here) {
+    nb_here = B - b0 < even ? B - b0 : even;
+    int helpers = c->cus / nb_here - 1;
+    if (helpers > njobs) helpers = njobs;
     PArgs a = {};
     a.fault_panel = -1;
     a.K = K + b0 * nn;
@@ -937,9 +951,10 @@ int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv,
   B7_TRY(persist_jobs(c, nb, 1, &jobs, &njobs));
   const int64_t nn = (int64_t)n * n;
   const int fw = (int)persist_flag_words(nb);
-  const int max_per_launch = c->cus / 4 > 0 ? c->cus / 4 : 1;  // at least three helpers per fit
+  const int max_per_launch = fits_per_launch(c, nb, true);
+  const int nlaunch = (B + max_per_launch - 1) / max_per_launch, even = (B + nlaunch - 1) / nlaunch;
   for (int b0 = 0; b0 < B;) {
-    const int left = B - b0, nb_here = left < max_per_launch ? left : max_per_launch;
+    const int left = B - b0, nb_here = left < even ? left : even;
     int helpers = c->cus / nb_here - 1;
     if (helpers > njobs) helpers = njobs;
     PArgs a = {};
