@@ -650,56 +650,96 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
 
 // L z = r by forward substitution, block row by block row as the tiles of L are published; |z|^2 and sum log L_ii are
 // all the likelihood needs (no inverse, no alpha).  One workgroup per fit; thread t: row t >> 2, a quarter of the columns.
-__device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok, int &turn) {
+__device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok, int &turn, unsigned long long *st) {
   const int n = a.n, nb = a.nb, tid = threadIdx.x, row = tid >> 2, part = tid & 3;
-  double *z = sm, *accs = sm + 64 * 64, *red = accs + 64;
+  unsigned long long t_wait = 0, t_work = 0, t0 = 0;  // diagnostics only (st != nullptr)
+  double *z = sm, *accs = sm + 64 * 64, *red = accs + 64, *img0 = red + 512, *img1 = img0 + NB * DLD, *dsave = img1 + NB * DLD;
+  static_assert((2 * 64 * 64 + 64 + 512 + 2 * NB * DLD) * 8 <= PERSIST_LDS_BYTES, "vec_job: z, accs, red and two tile images");
   double ssq = 0.0, logdet = 0.0;
   for (int p = 0; p < nb; ++p) {
     double acc = 0.0;
-    for (int q = 0; q < p; ++q) {
-      if (!wg_wait(F.ready(p, q), F, a.info, sh_ok, turn, 50000 + p * 64 + q)) return false;
-      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(a.L + ((int64_t)p * NB) * n + (int64_t)q * NB);
-      d2_t v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = ld16_sc1(rs, (row * n + 16 * part + 2 * i) * 8);
+    // Row p's tiles L[p][0 .. p-1], one after the other.  Each is loaded the way the tile jobs load (one 16-byte chunk
+    // per lane, a wave reads two whole rows: the earlier form had every lane read its own 16 columns, 64 scattered
+    // 16-byte requests per instruction, 25 GB/s, and the chain trailed the factorisation by 0.45 ms at N = 2048),
+    // staged through an LDS image, and summed from there in the order it always had.  The next tile's loads are issued
+    // before this one is consumed; a flag is awaited for up to four tiles at once (tile (p, q + 1) is computed from
+    // tile (p, q), so its flag implies the earlier ones), the last tile of the row -- the late one -- by itself.
+    d2_t r0[8], r1[8], r2[8];  // a ring of three tiles in flight: the loads of tile q + 2 are issued before tile q is consumed
+    int seen = -1;             // tiles <= seen have had their flag observed
+    auto await = [&](int q) -> bool {
+      if (q <= seen) return true;
+      const int last = q >= p - 1 ? p - 1 : (q + 3 < p - 2 ? q + 3 : p - 2);
+      if (st) t0 = __builtin_amdgcn_s_memtime();
+      if (!wg_wait(F.ready(p, last), F, a.info, sh_ok, turn, 50000 + p * 64 + q)) return false;
+      if (st) t_wait += __builtin_amdgcn_s_memtime() - t0;
+      seen = last;
+      return true;
+    };
+    auto issue = [&](int q, d2_t (&v)[8]) -> bool {
+      if (q >= p) return true;
+      if (!await(q)) return false;
+      tile_load_sc1(v, a.L + ((int64_t)p * NB) * n + (int64_t)q * NB, n);
+      return true;
+    };
+    auto consume = [&](int q, const d2_t (&v)[8]) {
+      if (st) t0 = __builtin_amdgcn_s_memtime();
+      double *img = (q & 1) ? img1 : img0;  // two images: the barrier of tile q + 1 is what frees the image of tile q
+      tile_to_lds(v, img);
+      __syncthreads();
+      const double *tr = img + row * DLD + 16 * part, *zq = z + q * 64 + 16 * part;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        acc += v[i][0] * z[q * 64 + 16 * part + 2 * i];
-        acc += v[i][1] * z[q * 64 + 16 * part + 2 * i + 1];
+        acc += tr[2 * i] * zq[2 * i];
+        acc += tr[2 * i + 1] * zq[2 * i + 1];
+      }
+      if (st) t_work += __builtin_amdgcn_s_memtime() - t0;
+    };
+    if (!issue(0, r0) || !issue(1, r1)) return false;
+    for (int q = 0; q < p; q += 3) {
+      if (!issue(q + 2, r2)) return false;
+      consume(q, r0);
+      if (q + 1 < p) {
+        if (!issue(q + 3, r0)) return false;
+        consume(q + 1, r1);
+      }
+      if (q + 2 < p) {
+        if (!issue(q + 4, r1)) return false;
+        consume(q + 2, r2);
       }
     }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (part == 0) accs[row] = a.resid[p * 64 + row] - acc;
+    if (st) t0 = __builtin_amdgcn_s_memtime();
     if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, turn, 60000 + p)) return false;  // its barrier publishes accs
-    const __amdgpu_buffer_rsrc_t rd = tile_rsrc(a.dinv + (int64_t)p * NB * NB);
-    double sz = 0.0;
+    if (st) t_wait += __builtin_amdgcn_s_memtime() - t0;
+    double sz = 0.0, dii = 0.0;
     {
       d2_t v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = ld16_sc1(rd, (row * NB + 16 * part + 2 * i) * 8);
+      tile_load_sc1(v, a.dinv + (int64_t)p * NB * NB, NB);  // coalesced and through an image, as the row's tiles (the
+      tile_to_lds(v, img0);                                  // barrier inside the wait above has freed both images)
+      __syncthreads();
+      const double *tr = img0 + row * DLD + 16 * part;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        sz += v[i][0] * accs[16 * part + 2 * i];
-        sz += v[i][1] * accs[16 * part + 2 * i + 1];
+        sz += tr[2 * i] * accs[16 * part + 2 * i];
+        sz += tr[2 * i + 1] * accs[16 * part + 2 * i + 1];
       }
+      dii = img0[row * DLD + row];
     }
     sz += __shfl_xor(sz, 1);
     sz += __shfl_xor(sz, 2);
     if (part == 0) {
       z[p * 64 + row] = sz;
       ssq += sz * sz;
-      // log L_ii = -log inv(L_pp)_ii: the diagonal of a triangular inverse is the reciprocal diagonal (L_pp itself is
-      // not behind a flag)
-      const unsigned long long bits = __hip_atomic_load(
-          reinterpret_cast<const unsigned long long *>(a.dinv + (int64_t)p * NB * NB + row * NB + row), __ATOMIC_RELAXED,
-          __HIP_MEMORY_SCOPE_AGENT);
-      logdet -= log(__longlong_as_double((long long)bits));
+      dsave[p * 64 + row] = dii;  // log L_ii = -log inv(L_pp)_ii (the diagonal of a triangular inverse is the reciprocal
+                                  // diagonal); the logarithms are taken after the chain, all at once
     }
     __syncthreads();
   }
+  for (int e = tid; e < nb * 64; e += 256) logdet -= log(dsave[e]);  // fixed assignment of terms to threads: same bits every run
   red[tid] = part == 0 ? ssq : 0.0;
-  red[256 + tid] = part == 0 ? logdet : 0.0;
+  red[256 + tid] = logdet;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) {
@@ -711,6 +751,7 @@ __device__ bool vec_job(const PArgs &a, const Flags &F, double *sm, int *sh_ok, 
   if (tid == 0) {
     a.terms[0] = red[0];
     a.terms[1] = red[256];
+    if (st) st[2] = t_wait, st[3] = t_work;
   }
   return true;
 }
@@ -756,7 +797,7 @@ __global__ void __launch_bounds__(256) potrf_persist_kernel(PArgs a) {
     } else if (type == JOB_INV) {
       ok = inv_job(a, F, I, J, dsm, sh_ok, turn);
     } else if (type == JOB_VEC) {
-      ok = vec_job(a, F, dsm, sh_ok, turn);
+      ok = vec_job(a, F, dsm, sh_ok, turn, a.stamps ? a.stamps + a.nb * 8 + jid * 4 : nullptr);
     } else if (type == JOB_INV_DIAG) {  // inv(L)[p][p] = inv(L_pp): nobody inside the launch reads it
       ok = wg_wait(F.ready(I, I), F, a.info, sh_ok, turn, 40000 + I);
       if (ok) {
@@ -934,6 +975,14 @@ int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv,
     a.sinfo = 4;
     a.resid = resid + (int64_t)b0 * n;
     a.terms = terms + 2 * b0;
+    if (c->persist_stamps && B == 1) {  // diagnostics (tools/persist_stamps.py N nll)
+      const size_t words = (size_t)nb * 8 + (size_t)njobs * 4;
+      B7_TRY(b7_ensure(c, c->pstamps, sizeof(unsigned long long) * words));
+      B7_HIP(c, hipMemsetAsync(c->pstamps.p, 0, sizeof(unsigned long long) * words, c->stream));
+      a.stamps = (unsigned long long *)c->pstamps.p;
+      c->pjobs_nb = nb;
+      c->pjobs_n = njobs;
+    }
     B7_TRY(persist_launch(c, a, nb_here, 2, helpers));
   }
   return B7_OK;

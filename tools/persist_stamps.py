@@ -1,5 +1,5 @@
 """Where the persistent Cholesky's critical workgroup spends its time, and when the helper jobs run (s_memtime stamps,
-B7_PERSIST_STAMPS=1).   python tools/persist_stamps.py [N]
+B7_PERSIST_STAMPS=1).   python tools/persist_stamps.py [N] [nll]      (nll: the likelihood mode, one fit of b7_gp_nll_batch)
 Critical path per panel p (cycles of the 100 MHz... no: s_memtime ticks = shader cycles at ~2.4 GHz under light load):
   0 factor start | 1 factor end (waves 1..3 finish the previous look-ahead inside its first step) | 2 both next tiles
   waited for / issued | 3 L_pp, inv(L_pp) stored, tiles in LDS | 4 triangular solve done | 5 inv(L_pp) published |
@@ -21,8 +21,13 @@ X = c.grid_sobol(N, d, 2)
 Y = benchmarks.ackley(X)
 amp = float(np.var(Y))
 hyp = (np.full(d, d / 8.0), amp, 1e-4 * amp, float(np.mean(Y)))
+NLL = len(sys.argv) > 2 and sys.argv[2] == "nll"
 for _ in range(3):
-    c.gp_fit(X, Y, *hyp)
+    if NLL:
+        c.gp_set_data(X, Y)
+        c.gp_nll_batch(hyp[0][None, :], hyp[1], hyp[2], hyp[3])
+    else:
+        c.gp_fit(X, Y, *hyp)
 L = _lib.load()
 buf = np.zeros(1 << 16, dtype=np.uint64)
 nb, nj = C.c_int(), C.c_int()
@@ -48,6 +53,10 @@ print("critical path total %.1f us (first factor start -> last factor end)" % ((
 print("workgroup 0: entry -> first factor %.1f us; last factor end -> exit %.1f us; entry -> exit %.1f us" % (
     (t0 - crit[nb - 1, 6]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 1]) / GHZ / 1e3, (crit[nb - 1, 7] - crit[nb - 1, 6]) / GHZ / 1e3))
 # job ends and workgroup 0's exit on the 100 MHz real-time counter (comparable across CUs)
+if NLL:
+    print("likelihood mode: job 0 is the vector job (L z = r); it ends %.1f us after workgroup 0 left; %.1f us in flag waits, "
+          "%.1f us loading and accumulating tiles" % ((jobs[0, 1] - crit[nb - 1, 5]) / 100.0, jobs[0, 2] / GHZ / 1e3, jobs[0, 3] / GHZ / 1e3))
+    jobs[0, 2:] = 0
 lag = (jobs[:, 1] - crit[nb - 1, 5]) / 100.0
 late = np.argsort(-lag)[:8]
 print("helper jobs still running after workgroup 0 left: %d; the last ends %.1f us later; latest job ids %s (lag us %s)" % (
