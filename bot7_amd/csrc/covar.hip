@@ -392,7 +392,10 @@ int launch_kxx_batch(b7_ctx *c, int B, const double *ls_dev, const double *amp_d
   o.batch.s_zsh = Npad;
   o.batch.s_out = (int64_t)Npad * Npad;
   o.batch.amp = amp_dev;
-  B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, 1, B), (const double *)c->xobs.p, 0, c->N, d, o, nullptr, 0.0, K, nullptr));
+  // as launch_kxx: with few fits the observations are split over blockIdx.y so that the grid still covers the chip
+  int ny = 1;
+  while (ny < 16 && (Npad / 64) % (ny * 2) == 0 && (Npad / KQ) * ny * B < 2 * c->cus) ny *= 2;
+  B7_TRY(ksx_dispatch(c, dim3(Npad / KQ, ny, B), (const double *)c->xobs.p, 0, c->N, d, o, nullptr, 0.0, K, nullptr));
   const int64_t total = (int64_t)Npad * Npad;
   hipLaunchKernelGGL(kxx_fix_kernel, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, c->stream, K, c->N, Npad, 0.0,
                      noise_dev, total);
