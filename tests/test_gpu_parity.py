@@ -507,6 +507,30 @@ def test_eval_nominate_more_hyper_samples_than_fit_side_by_side(ctx, orc):
         ctx.gp_predict()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_eval_nominate_random_shapes(ctx, orc, seed):
+    """Seeded random (N, d, M, S, score): ragged N incl. panel boundaries, tiny and mid-sized grids, one to seven hyper
+    samples -- the one-call path (fits side by side) against the separate calls, bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.choice([2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 257, 300]))
+    d = int(rng.integers(1, 9))
+    M = int(rng.choice([64, 100, 257, 1000, 4097]))
+    S = int(rng.integers(1, 8))
+    kind = "ei" if rng.random() < 0.5 else "cb"
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, d, N, M, lambda X: np.cos(2.5 * X).sum(axis=1, keepdims=True) + X[:, :1] ** 2)
+    hyps = [dict(hyp, lenscale_sq=hyp["lenscale_sq"] * float(rng.uniform(0.6, 1.6)), amp=hyp["amp"] * float(rng.uniform(0.8, 1.3)),
+                 noise=hyp["noise"] * float(rng.uniform(0.5, 20.0)), mean=hyp["mean"] + float(rng.normal(scale=0.05)))
+            for _ in range(S)]
+    ctx.grid_upload(X_hid)
+    val0, idx0, scores0 = _hip_nominate(ctx, X_obs, Y, hyps, kind)
+    ctx.gp_set_data(X_obs, Y)
+    kw = {"score": "ei", "fmin": [float(Y.min())]} if kind == "ei" else {"score": "cb"}
+    val1, idx1 = ctx.eval_nominate(hyps, **kw)
+    _, _, scores1 = ctx.score_finish(1.0, download=True)
+    assert (val1, idx1) == (val0, idx0), (N, d, M, S, kind)
+    assert np.array_equal(scores1, scores0), (N, d, M, S, kind)
+
+
 def test_eval_nominate_with_fantasy_columns(ctx, orc):
     """c > 1 response columns (the fantasies of scores/expected_improvement.lua:51-60): EI is the row mean over the
     columns (:83-85); one call against the separate entry points and against the oracle."""

@@ -217,6 +217,29 @@ def test_gp_identities_high_precision(orc):
     mpmath.mp.dps = 15
 
 
+def test_gp_oracle_matches_scikit_learn(orc):
+    """An independent third-party implementation of the same textbook algebra: scikit-learn's GaussianProcessRegressor
+    with a fixed ConstantKernel x anisotropic RBF (length_scale^2 = lenscale_sq, i.e. pdist's `lenscale`,
+    utils/math.lua:65-111), alpha = noise, no optimiser, the constant mean subtracted by hand.  Posterior mean, latent
+    variance and log marginal likelihood agree to 1e-11.  (It is not the reference's `gp` rock -- that stays absent and
+    the GP parity stays formally unpinned -- but it is not this repository's arithmetic either.)"""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel
+    rng = np.random.default_rng(5)
+    for N, M, d in ((40, 25, 4), (7, 9, 1), (120, 30, 6)):
+        X, Xs = rng.random((N, d)), rng.random((M, d))
+        Y = np.sin(3 * X.sum(1)).reshape(-1, 1)
+        ls, amp, noise, mean = rng.uniform(0.2, 1.0, size=d), 1.3, 1e-3, 0.2
+        k = ConstantKernel(amp, constant_value_bounds="fixed") * RBF(length_scale=np.sqrt(ls), length_scale_bounds="fixed")
+        g = GaussianProcessRegressor(kernel=k, alpha=noise, optimizer=None, normalize_y=False).fit(X, Y[:, 0] - mean)
+        mu, sd = g.predict(Xs, return_std=True)
+        f = orc.gp.fit(X, Y, ls, amp, noise, mean)
+        mu_o, var_o = orc.gp.predict(f, Xs)
+        assert np.abs(mu + mean - mu_o[:, 0]).max() < 1e-11
+        assert np.abs(sd ** 2 - var_o).max() < 1e-11 * amp
+        assert abs(g.log_marginal_likelihood_value_ + f.nll[0]) < 1e-9 * abs(f.nll[0])
+
+
 def test_gp_interpolates_when_nearly_noiseless(orc):
     rng = np.random.default_rng(11)
     X = rng.random((20, 2))
