@@ -240,6 +240,24 @@ def test_gp_oracle_matches_scikit_learn(orc):
         assert abs(g.log_marginal_likelihood_value_ + f.nll[0]) < 1e-9 * abs(f.nll[0])
 
 
+def test_blr_oracle_mean_is_ridge_regression():
+    """The Bayesian-linear head of DNGO (models/dngo.lua:174, gp.models.bayes_linear -- absent): its posterior mean is ridge
+    regression with lambda = alpha / beta, checked against scikit-learn's Ridge (an implementation that is not this
+    repository's); the predictive variance 1/beta + phi' S phi against the explicit inverse."""
+    from sklearn.linear_model import Ridge
+    from oracle import blr
+    rng = np.random.default_rng(3)
+    N, z, M = 80, 12, 30
+    Z0, Z1, w = rng.normal(size=(N, z)), rng.normal(size=(M, z)), rng.normal(size=z)
+    Y = (Z0 @ w + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    a, b, mean = 2.0, 50.0, 0.3
+    mu, var = blr.predict(blr.fit(Z0, Y, a, b, mean), Z1)
+    r = Ridge(alpha=a / b, fit_intercept=False, solver="cholesky").fit(Z0, Y[:, 0] - mean)
+    assert np.abs(r.predict(Z1) + mean - np.asarray(mu).ravel()).max() < 1e-12
+    S = np.linalg.inv(b * Z0.T @ Z0 + a * np.eye(z))
+    assert np.abs(1 / b + np.einsum("ij,jk,ik->i", Z1, S, Z1) - np.asarray(var).ravel()).max() < 1e-14
+
+
 def test_gp_interpolates_when_nearly_noiseless(orc):
     rng = np.random.default_rng(11)
     X = rng.random((20, 2))
