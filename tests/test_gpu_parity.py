@@ -379,7 +379,7 @@ def test_marginalised_argmax_matches_oracle(ctx, orc, kind, d, N, M, obj, S):
 
 
 @pytest.mark.parametrize("N,d,M", [(700, 6, 70000), (100, 3, 66000), (2048, 32, 65536 + 256), (2, 2, 65536), (129, 3, 65537),
-                                   (300, 6, 66000), (513, 4, 65700), (1000, 16, 65536), (1500, 6, 66001)])
+                                   (300, 6, 66000), (513, 4, 65700), (1000, 16, 65536), (1500, 6, 66001), (4096, 8, 65536), (2304, 5, 65600)])
 def test_posterior_grid_shapes_are_bit_identical(ctx, orc, N, d, M):
     """The large-grid shapes (n-tiles of 256 rows when the padded N is a multiple of 256 -- N = 700, 2048 --, otherwise
     256-candidate workgroups on 128-row n-tiles -- N = 100) and the small-grid shape (128-candidate workgroups) give the
