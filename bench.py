@@ -329,7 +329,7 @@ def main():
                                   "(b7_score_finish_global: %s)"
                                   % (world, "ncclAllReduce inside libbot7hip.so" if rccl else "gloo rehearsal"),
                    "device": info["name"]},
-        "roofline": {"bound": "mfma", "kernel": "post_kernel_w4 (posterior variance: L^-1 K*' with fused column sumsq)",
+        "roofline": {"bound": "mfma", "kernel": "post_kernel_w4t (posterior variance: L^-1 K*' with fused column sumsq; 256-row n-tiles)",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS if achieved == achieved else None,
                      "traffic": traffic,
@@ -337,7 +337,7 @@ def main():
                                         "the same launch shape)" % traffic_src) if traffic_src else None,
                      "algorithmic_bytes_per_launch": rows_per_launch * N * 8.0,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": post_avg_s * 1e3,
-                     "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s at 2.4 GHz; in-kernel clock under this load 2.31 GHz, "
+                     "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s at 2.4 GHz; in-kernel clock under this load 2.33-2.38 GHz, "
                              "MFMA issue efficiency 96 % (profiles/r02_post_clock.txt, tools/post_clock.py)"},
         "gp_fit_ms": fit_ms,
         "ksx_hbm_gbs": ksx_gbs, "ksx_hbm_frac": (ksx_gbs / HBM_PEAK_GBS) if ksx_gbs else None,
