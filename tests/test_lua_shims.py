@@ -126,3 +126,32 @@ def test_shims_speak_the_driver_protocol():
     for f in lua_files():
         assert "torch.data(" + "t:contiguous())" not in open(os.path.join(LUA, f)).read(), f
         assert not re.search(r"torch\.data\(\s*[A-Za-z_0-9.]+:contiguous\(\)\s*\)", open(os.path.join(LUA, f)).read()), f
+
+
+def test_lua_blocks_and_brackets_balance():
+    """No Lua runtime here: at least every block opener (function / if / do / repeat) has its end / until and every bracket
+    its partner, comments and strings stripped -- the gross syntax errors a missing `end` would be."""
+    def strip(src):
+        src = re.sub(r"--\[\[.*?\]\]", "", src, flags=re.S)
+        src = re.sub(r"--[^\n]*", "", src)
+        src = re.sub(r"\[\[.*?\]\]", "''", src, flags=re.S)
+        src = re.sub(r"'(?:\\.|[^'\\])*'", "''", src)
+        src = re.sub(r'"(?:\\.|[^"\\])*"', '""', src)
+        return src
+    for f in lua_files():
+        src = strip(open(os.path.join(LUA, f)).read())
+        bal, pending_do = 0, 0
+        for t in re.findall(r"\b(function|if|for|while|do|repeat|until|end)\b", src):
+            if t in ("for", "while"):
+                pending_do += 1          # their `do` opens the block
+            elif t == "do":
+                pending_do = max(0, pending_do - 1)
+                bal += 1
+            elif t in ("function", "if", "repeat"):
+                bal += 1
+            else:
+                bal -= 1
+            assert bal >= 0, "%s: an `end` without an opener" % f
+        assert bal == 0, "%s: %d block(s) left open" % (f, bal)
+        for a, b in ("()", "{}", "[]"):
+            assert src.count(a) == src.count(b), "%s: unbalanced %s%s" % (f, a, b)
