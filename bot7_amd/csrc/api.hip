@@ -171,7 +171,7 @@ void b7_destroy(b7_ctx *c) {
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
                    &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pstamps,
                    &c->bhyp, &c->bw, &c->bzsc, &c->bzss, &c->bK, &c->bL, &c->bdinv, &c->bflags, &c->binfo, &c->bresid, &c->bterms,
-                   &c->bLinv, &c->balpha};
+                   &c->bLinv, &c->balpha, &c->bmu, &c->bvar};
   for (auto &kv : c->pjobs_cache) b7_release(kv.second.buf);
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
@@ -767,28 +767,52 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
                             (unsigned *)c->bflags.p, (int *)c->binfo.p));
     B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p));
     B7_HIP(c, hipMemcpyAsync(reports, c->binfo.p, rep_bytes, hipMemcpyDeviceToHost, c->stream));
-    // the posterior kernels read the fit through the context: point it at one sample's slot after the other
-    void *const zsc0 = c->zsc.p, *const zss0 = c->zss.p, *const w0 = c->w.p, *const alpha0 = c->alpha.p, *const linv0 = c->Linv.p;
-    int rc = B7_OK;
-    for (int s = 0; s < S && rc == B7_OK; ++s) {
-      c->zsc.p = (double *)c->bzsc.p + (size_t)s * n * c->dpad;
-      c->zss.p = (double *)c->bzss.p + (size_t)s * n;
-      c->w.p = (double *)c->bw.p + (size_t)s * c->dpad;
-      c->alpha.p = (double *)c->balpha.p + (size_t)s * n;
-      c->Linv.p = (double *)c->bLinv.p + s * nn;
-      c->amp = hyps[s].amp;
-      c->noise = hyps[s].noise;
-      c->mean = hyps[s].mean;
-      c->model_kind = 0;
-      c->fitted = true;
-      rc = predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p);
-      if (rc == B7_OK) rc = score_add(c, spec, fd);
+    const size_t row_bytes = sizeof(double) * (size_t)n;
+    const int64_t Mpad = round_up(c->M, B7_MROWS);
+    if ((size_t)Mpad * S * row_bytes <= c->ks_bytes) {
+      // K* of all S samples fits the workspace at once (the reference's default sizes: 2e4 candidates, tens to hundreds
+      // of observations, 10 samples): K*, posterior and score:add of all samples in ONE launch each (grid.z / grid.y =
+      // sample), the score summed over the samples in order inside the kernel
+      B7_TRY(b7_ensure(c, c->ks, (size_t)Mpad * S * row_bytes));
+      B7_TRY(b7_ensure(c, c->bmu, sizeof(double) * (size_t)S * c->M));
+      B7_TRY(b7_ensure(c, c->bvar, sizeof(double) * (size_t)S * c->M));
+      B7_TRY(launch_ksx_batch(c, S, (const double *)c->grid[c->grid_cur].p, Mpad, c->M, (const double *)c->bw.p,
+                              (const double *)c->bzsc.p, (const double *)c->bzss.p, amp_dev, mean_dev,
+                              (const double *)c->balpha.p, (double *)c->ks.p, (int64_t)Mpad * n, (double *)c->bmu.p, c->M));
+      B7_TRY(launch_post_batch(c, S, (const double *)c->bLinv.p, (const double *)c->ks.p, (int64_t)Mpad * n, Mpad, c->M,
+                               (double *)c->bvar.p, c->M, amp_dev, noise_dev));
+      if (spec->kind == B7_SCORE_EI)
+        B7_TRY(launch_ei_batch(c, S, (const double *)c->bmu.p, (const double *)c->bvar.p, c->M, fd, spec->tradeoff, c->M,
+                               (double *)c->acc.p));
+      else
+        B7_TRY(launch_cb_batch(c, S, (const double *)c->bmu.p, (const double *)c->bvar.p, c->M, spec->tradeoff, spec->upper,
+                               spec->sign, c->M, (double *)c->acc.p));
+      c->fitted = false;     // neither the context's fit slot nor its mean / variance vectors hold any of these samples
+      c->predicted = false;
+    } else {
+      // the posterior kernels read the fit through the context: point it at one sample's slot after the other
+      void *const zsc0 = c->zsc.p, *const zss0 = c->zss.p, *const w0 = c->w.p, *const alpha0 = c->alpha.p, *const linv0 = c->Linv.p;
+      int rc = B7_OK;
+      for (int s = 0; s < S && rc == B7_OK; ++s) {
+        c->zsc.p = (double *)c->bzsc.p + (size_t)s * n * c->dpad;
+        c->zss.p = (double *)c->bzss.p + (size_t)s * n;
+        c->w.p = (double *)c->bw.p + (size_t)s * c->dpad;
+        c->alpha.p = (double *)c->balpha.p + (size_t)s * n;
+        c->Linv.p = (double *)c->bLinv.p + s * nn;
+        c->amp = hyps[s].amp;
+        c->noise = hyps[s].noise;
+        c->mean = hyps[s].mean;
+        c->model_kind = 0;
+        c->fitted = true;
+        rc = predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p);
+        if (rc == B7_OK) rc = score_add(c, spec, fd);
+      }
+      c->zsc.p = zsc0, c->zss.p = zss0, c->w.p = w0, c->alpha.p = alpha0, c->Linv.p = linv0;
+      c->fitted = false;  // the context's own fit slot does not hold any of these fits
+      c->predicted = true;
+      c->Mpred = c->M;
+      B7_TRY(rc);
     }
-    c->zsc.p = zsc0, c->zss.p = zss0, c->w.p = w0, c->alpha.p = alpha0, c->Linv.p = linv0;
-    c->fitted = false;  // the context's own fit slot does not hold any of these fits
-    c->predicted = true;
-    c->Mpred = c->M;
-    B7_TRY(rc);
   } else {
     for (int s = 0; s < S; ++s) {
       B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));

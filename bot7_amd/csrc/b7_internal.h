@@ -110,7 +110,7 @@ struct b7_ctx {
   DevBuf pstamps;  // diagnostics (B7_PERSIST_STAMPS)
   int pjobs_nb = 0, pjobs_n = 0;   // shape of the last single persistent launch (for the stamp reader)
   // b7_gp_nll_batch: B fits of the resident data in likelihood mode
-  DevBuf bhyp, bw, bzsc, bzss, bK, bL, bdinv, bflags, binfo, bresid, bterms, bLinv, balpha;
+  DevBuf bhyp, bw, bzsc, bzss, bK, bL, bdinv, bflags, binfo, bresid, bterms, bLinv, balpha, bmu, bvar;
   bool persist_attr_set = false, persist_stamps = false;
   int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
@@ -187,6 +187,10 @@ int launch_gather_rows(b7_ctx *c, const double *src, double *out, const int64_t 
 struct KBatchDesc {   // a batch of fits over the same observations: strides (doubles) per fit, per-fit amplitudes
   int64_t s_w = 0, s_zsc = 0, s_zsh = 0, s_out = 0;
   const double *amp = nullptr;
+  // the posterior mean of every fit alongside (K(X*,X) of a batch of fits over the same candidates): per-fit alpha stride,
+  // constant means, output stride
+  int64_t s_alpha = 0, s_mu = 0;
+  const double *mean = nullptr;
 };
 struct ObsSet {
   const double *zsc;  // npad x dpad scaled observations
@@ -200,6 +204,13 @@ int launch_prep_obs_aux(b7_ctx *c, const double *xobs, const double *ls_dev, int
 int launch_k_generic(b7_ctx *c, const double *xq, int64_t rows, int64_t Mtotal, const ObsSet &o, double *out);
 int launch_prep_obs(b7_ctx *c, const double *xobs, const double *lenscale_sq_dev, int N, int d);
 int launch_kxx(b7_ctx *c, double diag_add);
+int launch_ksx_batch(b7_ctx *c, int S, const double *xq, int64_t rows, int64_t Mtotal, const double *w, const double *zsc,
+                     const double *zss, const double *amp_dev, const double *mean_dev, const double *alpha, double *ks,
+                     int64_t s_out, double *mu, int64_t s_mu);
+int launch_ei_batch(b7_ctx *c, int S, const double *mu, const double *var, int64_t stride, const double *fmin_dev,
+                    double tradeoff, int64_t M, double *acc);
+int launch_cb_batch(b7_ctx *c, int S, const double *mu, const double *var, int64_t stride, double tradeoff, int upper,
+                    double sign, int64_t M, double *acc);
 int launch_kxx_batch(b7_ctx *c, int B, const double *ls_dev, const double *amp_dev, const double *noise_dev, double *w,
                      double *zsc, double *zss, double *K);
 int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t Mtotal, int d, double *ks,
@@ -223,6 +234,8 @@ int launch_set_identity(b7_ctx *c);    // L = I (Npad x Npad), dinv = identity b
 
 // posterior.hip
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var);
+int launch_post_batch(b7_ctx *c, int S, const double *Linv, const double *ks, int64_t sks, int64_t rows, int64_t Mtotal,
+                      double *var, int64_t svar, const double *amp_dev, const double *noise_dev);
 
 // extras.hip
 int launch_mean_multi(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *mu);

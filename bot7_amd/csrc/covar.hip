@@ -132,6 +132,11 @@ __global__ void __launch_bounds__(256)
     zsh += bz * kb.s_zsh;
     out += bz * kb.s_out;
     amp = kb.amp[bz];
+    if (kb.mean) {  // the batch carries its own alpha / mean / mu per fit
+      alpha += bz * kb.s_alpha;
+      mu += bz * kb.s_mu;
+      meanc = kb.mean[bz];
+    }
   }
   constexpr int KO = ksx_slab(DPAD);
   constexpr int TPR = 256 / KO;                       // staging threads per slab row
@@ -378,6 +383,26 @@ int launch_kxx(b7_ctx *c, double diag_add) {
 
 // ---- B fits over the same observations: per-fit scaled observations, then K_b = amp_b exp(-D_b / 2) + noise_b I ---------
 // ls: B x d, amp / noise: B (device).  zsc: B x Npad x dpad, zss: B x Npad, w: B x dpad, K: B x Npad x Npad.
+// K(X*, X) and the posterior mean of S fits over the same candidate rows in one launch (grid.z = fit): the hyper samples
+// of a nomination whose K* fits the workspace S times over (b7_eval_nominate)
+int launch_ksx_batch(b7_ctx *c, int S, const double *xq, int64_t rows, int64_t Mtotal, const double *w, const double *zsc,
+                     const double *zss, const double *amp_dev, const double *mean_dev, const double *alpha, double *ks,
+                     int64_t s_out, double *mu, int64_t s_mu) {
+  PhaseScope ps(c, "ksx");
+  if (rows % KQ) return b7_fail(c, B7_ERR_INVALID, "ksx: rows %lld not a multiple of %d", (long long)rows, KQ);
+  ObsSet o{zsc, zss, c->Npad};
+  o.w = w;
+  o.batch.s_w = c->dpad;
+  o.batch.s_zsc = (int64_t)c->Npad * c->dpad;
+  o.batch.s_zsh = c->Npad;
+  o.batch.s_out = s_out;
+  o.batch.amp = amp_dev;
+  o.batch.s_alpha = c->Npad;
+  o.batch.s_mu = s_mu;
+  o.batch.mean = mean_dev;
+  return ksx_dispatch(c, dim3((unsigned)(rows / KQ), 1, S), xq, 0, Mtotal, c->dfit, o, alpha, 0.0, ks, mu);
+}
+
 int launch_kxx_batch(b7_ctx *c, int B, const double *ls_dev, const double *amp_dev, const double *noise_dev, double *w,
                      double *zsc, double *zss, double *K) {
   PhaseScope ps(c, "kxx");

@@ -43,6 +43,14 @@ extern "C" int b7dbg_post_stamps(unsigned long long *out, int nblocks) {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
+// Several fits over the same candidates in one launch (b7_eval_nominate: the hyper samples of a nomination): grid.y = fit;
+// L^-1, K* and the output are strided per fit, amp (and the noise term when the variance includes it) come from arrays.
+// base == nullptr: a single fit, the scalar arguments apply.
+struct PostBatch {
+  int64_t sLinv = 0, sks = 0, svar = 0;
+  const double *base = nullptr, *var_add = nullptr;
+};
+
 // ---- one wave per SIMD, one continuous MFMA stream -----------------------------------------------------------------------
 // Four waves (512 registers each); a wave owns all 128 rows of the n-tile and 16 NJ candidates: 8 x NJ accumulator
 // tiles of 16 x 16 (NJ = 4: 128 x 256 workgroup tile; NJ = 2: 128 x 128, for grids with fewer than one 256-candidate
@@ -214,9 +222,18 @@ __device__ __forceinline__ void stage(Frags<NJ> &f0, Frags<NJ> &f1, Stage<NJ> &g
 template <int NJ>
 __global__ void __launch_bounds__(256)
     post_kernel_w4(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0, int64_t Mtotal,
-                   double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var) {
+                   double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var,
+                   PostBatch bat) {
   constexpr int BN = 64 * NJ, STAGE_DBL = (BM + BN) * LD, NC = 4 + 2 * NJ, NP = 8 + NJ;
   extern __shared__ __align__(16) double sm[];
+  if (bat.base) {
+    const int64_t y = blockIdx.y;
+    Linv += y * bat.sLinv;
+    ks += y * bat.sks;
+    var += y * bat.svar;
+    base = bat.base[y];
+    if (bat.var_add) var_add = bat.var_add[y];
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef B7_POST_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
@@ -435,10 +452,19 @@ struct Tall {
 template <int NJ, int NR>
 __global__ void __launch_bounds__(256)
     post_kernel_w4t(const double *__restrict__ Linv, const double *__restrict__ ks, int Npad, int64_t row0, int64_t Mtotal,
-                    double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var) {
+                    double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var,
+                    PostBatch bat) {
   using T = Tall<NJ, NR>;
   constexpr int BMT = T::BMT, BN = T::BN, NC = T::NC, NP = T::NP;
   extern __shared__ __align__(16) double sm[];
+  if (bat.base) {
+    const int64_t y = blockIdx.y;
+    Linv += y * bat.sLinv;
+    ks += y * bat.sks;
+    var += y * bat.svar;
+    base = bat.base[y];
+    if (bat.var_add) var_add = bat.var_add[y];
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef B7_POST_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
@@ -534,40 +560,67 @@ __global__ void __launch_bounds__(256)
 
 #ifndef B7_POST_NO_LAUNCHERS
 namespace {
+struct PostArgs {  // what one launch needs besides the kernel: S fits side by side (S = 1: the context's own fit)
+  const double *Linv, *ks;
+  double *var;
+  double base, sgn, var_add;
+  int S;
+  PostBatch pb;
+};
+
 template <int NJ>
-int launch_post_w4(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
+int launch_post_w4(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
   constexpr int lds = w4::lds_bytes<NJ>();
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(w4::post_kernel_w4<NJ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const bool blr = c->model_kind == 1;
-  hipLaunchKernelGGL(w4::post_kernel_w4<NJ>, dim3((unsigned)(rows / (64 * NJ))), dim3(256), lds, c->stream,
-                     (const double *)c->Linv.p, ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
-                     blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
+  hipLaunchKernelGGL(w4::post_kernel_w4<NJ>, dim3((unsigned)(rows / (64 * NJ)), a.S), dim3(256), lds, c->stream, a.Linv, a.ks,
+                     c->Npad, row0, Mtotal, a.base, a.sgn, a.var_add, c->opts.var_clamp, c->opts.var_min, a.var, a.pb);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
-}  // namespace
 
 template <int NJ, int NR>
-static int launch_post_tall(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
+int launch_post_tall(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
   using T = w4::Tall<NJ, NR>;
   auto kern = w4::post_kernel_w4t<NJ, NR>;
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));
-  const bool blr = c->model_kind == 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / T::BN)), dim3(256), T::LDS_BYTES, c->stream,
-                     (const double *)c->Linv.p, ks, c->Npad, row0, Mtotal, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
-                     blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), c->opts.var_clamp, c->opts.var_min, var);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(rows / T::BN), a.S), dim3(256), T::LDS_BYTES, c->stream, a.Linv, a.ks, c->Npad, row0,
+                     Mtotal, a.base, a.sgn, a.var_add, c->opts.var_clamp, c->opts.var_min, a.var, a.pb);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
 
+int dispatch_post(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
+  if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
+  const bool large = rows / 256 * a.S >= c->cus;  // at least one 256-candidate workgroup per CU
+  // large grids: the tall shape (n-tiles of 256 rows: half the K* bytes through the L2) when the padded N allows it
+  if (c->Npad % 256 == 0 && large) return launch_post_tall<2, 16>(c, a, row0, rows, Mtotal);
+  // 256 candidates per workgroup when that still gives every CU one; otherwise 128 (same arithmetic, same bits)
+  if (!large) return launch_post_w4<2>(c, a, row0, rows, Mtotal);
+  return launch_post_w4<4>(c, a, row0, rows, Mtotal);
+}
+}  // namespace
+
 int launch_post(b7_ctx *c, const double *ks, int64_t row0, int64_t rows, int64_t Mtotal, double *var) {
   PhaseScope ps(c, "post");
-  // large grids: the tall shape (n-tiles of 256 rows: half the K* bytes through the L2) when the padded N allows it
-  if (c->Npad % 256 == 0 && rows / 256 >= c->cus) return launch_post_tall<2, 16>(c, ks, row0, rows, Mtotal, var);
-  // 256 candidates per workgroup when that still gives every CU one; otherwise 128 (same arithmetic, same bits)
-  if (rows / 256 < c->cus) return launch_post_w4<2>(c, ks, row0, rows, Mtotal, var);
-  return launch_post_w4<4>(c, ks, row0, rows, Mtotal, var);
+  const bool blr = c->model_kind == 1;
+  PostArgs a{(const double *)c->Linv.p, ks, var, blr ? 0.0 : c->amp, blr ? 1.0 : -1.0,
+             blr ? c->noise : (c->opts.var_with_noise ? c->noise : 0.0), 1, PostBatch{}};
+  return dispatch_post(c, a, row0, rows, Mtotal);
+}
+
+// S GP fits over the same rows: Linv_s = Linv + s Npad^2, K*_s = ks + s sks, var_s = var + s svar; amp_s (and noise_s) on
+// the device
+int launch_post_batch(b7_ctx *c, int S, const double *Linv, const double *ks, int64_t sks, int64_t rows, int64_t Mtotal,
+                      double *var, int64_t svar, const double *amp_dev, const double *noise_dev) {
+  PhaseScope ps(c, "post");
+  PostArgs a{Linv, ks, var, 0.0, -1.0, 0.0, S, PostBatch{}};
+  a.pb.sLinv = (int64_t)c->Npad * c->Npad;
+  a.pb.sks = sks;
+  a.pb.svar = svar;
+  a.pb.base = amp_dev;
+  a.pb.var_add = c->opts.var_with_noise ? noise_dev : nullptr;
+  return dispatch_post(c, a, 0, rows, Mtotal);
 }
 #endif

@@ -76,6 +76,41 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// S hyper samples at once (one response column): acc[j] = ((acc[j] + score_0) + score_1) + ... in sample order, exactly
+// what S score:add calls leave (bots/bayesopt.lua:76)
+__global__ void __launch_bounds__(256)
+    ei_batch_kernel(const double *__restrict__ mu, const double *__restrict__ var, int S, int64_t sstride,
+                    const double *__restrict__ fmin, double xi, int64_t M, double *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
+    double a = out[j];
+    for (int s = 0; s < S; ++s) {
+      double sigma = sqrt(var[s * sstride + j]);
+      double imprv = (fmin[0] + (-mu[s * sstride + j])) + (-xi);
+      double z = imprv / sigma;
+      double ei = (imprv * b7_norm_cdf(z)) + (sigma * b7_norm_pdf(z));
+      ei = (ei < 0.0) ? 0.0 : ei;
+      a = a + ei;
+    }
+    out[j] = a;
+  }
+}
+__global__ void __launch_bounds__(256)
+    cb_batch_kernel(const double *__restrict__ mu, const double *__restrict__ var, int S, int64_t sstride, double kappa,
+                    int upper, double sign, int64_t M, double *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
+    double a = out[j];
+    for (int s = 0; s < S; ++s) {
+      double sd = sqrt(var[s * sstride + j]) * kappa;
+      double v = upper ? (mu[s * sstride + j] + sd) : (mu[s * sstride + j] + (-sd));
+      v = (sign > 0.0) ? v : -v;
+      a = a + v;
+    }
+    out[j] = a;
+  }
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(double *__restrict__ p, int64_t n, double v) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) p[j] = v;
@@ -180,6 +215,26 @@ int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, i
   if (M <= 0) return B7_OK;
   hipLaunchKernelGGL(cb_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, tradeoff, upper, sign, M,
                      ycols, out, accumulate ? 1 : 0);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_ei_batch(b7_ctx *c, int S, const double *mu, const double *var, int64_t stride, const double *fmin_dev,
+                    double tradeoff, int64_t M, double *acc) {
+  PhaseScope ps(c, "score");
+  if (M <= 0) return B7_OK;
+  hipLaunchKernelGGL(ei_batch_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, S, stride, fmin_dev, tradeoff, M,
+                     acc);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_cb_batch(b7_ctx *c, int S, const double *mu, const double *var, int64_t stride, double tradeoff, int upper,
+                    double sign, int64_t M, double *acc) {
+  PhaseScope ps(c, "score");
+  if (M <= 0) return B7_OK;
+  hipLaunchKernelGGL(cb_batch_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, S, stride, tradeoff, upper, sign,
+                     M, acc);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

@@ -269,10 +269,11 @@ int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offse
  * back and the host synchronises once: each fit's pivot report is checked afterwards, and a failed pivot (or a
  * hand-off time-out) redoes the nomination through the per-sample path with utils/math.lua:159-218's jitter
  * schedule.  With S > 1 and one response column the S fits run SIDE BY SIDE in one persistent launch (one critical
- * workgroup each): a fit's dependent chain leaves most of the chip idle, so ten fits cost little more than one.
+ * workgroup each): a fit's dependent chain leaves most of the chip idle, so ten fits cost little more than one;
+ * and when K(X*,X) of all S samples fits the workspace, K*, posterior and score:add of all samples are one launch each.
  * jitter_out / info_out: nullable, S entries (as b7_gp_fit's).  The accumulator holds score / S afterwards
- * (b7_score_finish with divisor 1 downloads it); the context's own fit slot holds none of the S fits (fit again
- * before b7_gp_predict). */
+ * (b7_score_finish with divisor 1 downloads it); the context's own fit slot and mean / variance vectors hold none of
+ * the S samples (fit again before b7_gp_predict / b7_score_*). */
 #define B7_SCORE_EI 1 /* scores/expected_improvement.lua: needs fmin[ycols]; tradeoff = xi */
 #define B7_SCORE_CB 2 /* scores/confidence_bound.lua: tradeoff = kappa, upper, sign as b7_score_cb */
 typedef struct {

@@ -27,14 +27,14 @@ int main(int argc, char **argv) {
   {
     auto kern = w4::post_kernel_w4<4>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, w4::lds_bytes<4>());
-    hipLaunchKernelGGL(kern, dim3(M / 256), dim3(256), w4::lds_bytes<4>(), 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    hipLaunchKernelGGL(kern, dim3(M / 256), dim3(256), w4::lds_bytes<4>(), 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV, PostBatch{});
     hipDeviceSynchronize();
     hipMemcpy(V4.data(), dV, M * 8, hipMemcpyDeviceToHost);
   }
   {
     auto kern = w4::post_kernel_w4<2>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, w4::lds_bytes<2>());
-    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), w4::lds_bytes<2>(), 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), w4::lds_bytes<2>(), 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV, PostBatch{});
     hipDeviceSynchronize();
     hipMemcpy(V2.data(), dV, M * 8, hipMemcpyDeviceToHost);
   }
@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
     using T = w4::Tall<2, 16>;
     auto kern = w4::post_kernel_w4t<2, 16>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3(M / T::BN), dim3(256), T::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV);
+    hipLaunchKernelGGL(kern, dim3(M / T::BN), dim3(256), T::LDS_BYTES, 0, dL, dK, Npad, (int64_t)0, (int64_t)M, 0.0, 1.0, 0.0, 0, 0.0, dV, PostBatch{});
     hipDeviceSynchronize();
     hipMemcpy(VT.data(), dV, M * 8, hipMemcpyDeviceToHost);
   }
