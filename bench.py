@@ -337,7 +337,7 @@ def main():
                                         "the same launch shape)" % traffic_src) if traffic_src else None,
                      "algorithmic_bytes_per_launch": rows_per_launch * N * 8.0,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": post_avg_s * 1e3,
-                     "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s at 2.4 GHz; in-kernel clock under this load 2.33-2.38 GHz, "
+                     "note": "fp64 v_mfma_f64_16x16x4 peak 78.6 TFLOP/s at 2.4 GHz; in-kernel clock under this load 2.29-2.38 GHz by device, "
                              "MFMA issue efficiency 96 % (profiles/r02_post_clock.txt, tools/post_clock.py)"},
         "gp_fit_ms": fit_ms,
         "ksx_hbm_gbs": ksx_gbs, "ksx_hbm_frac": (ksx_gbs / HBM_PEAK_GBS) if ksx_gbs else None,
