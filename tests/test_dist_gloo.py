@@ -66,3 +66,86 @@ def test_sharded_argmax_exchange_gloo(world):
         assert p.exitcode == 0
     for rank, out in results:
         assert all(out), "rank %d disagreed with the unsharded arg-max: %s" % (rank, out)
+
+
+class _OracleCtx(object):
+    """Stands in for bot7_amd.Context on a machine without a GPU: the calls ShardedScorer.eval_nominate makes on its gloo
+    path, answered by the oracle over this rank's rows."""
+
+    def __init__(self, X_obs, Y, X_shard):
+        from oracle import cport, gp
+        self.c, self.gp, self.X_obs, self.Y, self.X = cport, gp, X_obs, Y, X_shard
+        self.acc = None
+
+    def comm_info(self):
+        return (0, 1)                      # no communicator: the torch.distributed exchange is used
+
+    def gp_predict_hyp(self, lenscale_sq, amp, noise, mean):
+        f = self.gp.fit(self.X_obs, self.Y, lenscale_sq, amp, noise, mean)
+        self.mu, self.var = self.gp.predict(f, self.X)
+
+    def score_reset(self):
+        self.acc = np.zeros(self.X.shape[0])
+
+    def score_ei(self, fmin, tradeoff):
+        self.c.accumulate(self.acc, self.c.ei(self.mu, self.var, fmin, tradeoff))
+
+    def score_cb(self, tradeoff, upper, sign):
+        self.c.accumulate(self.acc, self.c.cb(self.mu, self.var, tradeoff, upper, sign))
+
+    def score_finish(self, divisor, download=False):
+        self.c.divide(self.acc, divisor)
+        i, v = self.c.argmax_first(self.acc)
+        return v, i, None
+
+
+def _nominate_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as td
+    from bot7_amd import benchmarks, dist
+    from oracle import cport, gp
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    d, N, M = 6, 40, 1501
+    pool = cport.sobol(M + N, d, 2)
+    X_obs, X_hid = pool[:N], pool[N:]
+    Y = benchmarks.hartmann6(X_obs)
+    amp = float(np.var(Y))
+    hyps = [{"lenscale_sq": np.full(d, d / 8.0) * (1.0 + 0.2 * s), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
+            for s in range(3)]
+    ok = []
+    for spec in ({"score": "ei", "fmin": [float(Y.min())], "tradeoff": 0.0}, {"score": "cb"}):
+        ctx = _OracleCtx(X_obs, Y, None)
+        shard = dist.ShardedScorer(ctx, M, rank, world)
+        ctx.X = X_hid[shard.lo:shard.hi]
+        val, idx = shard.eval_nominate(hyps, spec, device="cpu")
+        whole = _OracleCtx(X_obs, Y, X_hid)           # the unsharded nomination
+        for s, h in enumerate(hyps):
+            whole.gp_predict_hyp(h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
+            if s == 0:
+                whole.score_reset()
+            whole.score_ei(spec["fmin"], 0.0) if spec["score"] == "ei" else whole.score_cb(1.0, False, -1.0)
+        wv, wi, _ = whole.score_finish(3.0)
+        ok.append(idx == wi and val == wv)
+    td.barrier()
+    td.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_eval_nominate_gloo(world):
+    """bayesopt:eval + nominate over a grid sharded across ranks (the gloo path of ShardedScorer.eval_nominate: per-sample
+    calls on each shard, one (value, index) exchange): every rank gets the unsharded winner."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nominate_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok in results:
+        assert all(ok), "rank %d: sharded nomination differs from the unsharded one: %s" % (rank, ok)
