@@ -510,7 +510,7 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
   if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "gp_nll_batch: call b7_gp_set_data first");
   if (B < 1 || !lenscale_sq || !amp || !noise || !mean || !nll_out) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: bad arguments");
   if (c->ycols != 1) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_nll_batch: one response column only");
-  if (c->Npad > 2048) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_nll_batch: N > 2048 (evaluate with b7_gp_fit_hyp one by one)");
+  if (c->Npad > B7_PERSIST_NMAX) return b7_fail(c, B7_ERR_UNSUPPORTED, "gp_nll_batch: N > 4096 (evaluate with b7_gp_fit_hyp one by one)");
   const int N = c->N, n = c->Npad, d = c->dfit, dpad = c->dpad, nb = n / B7_PANEL;
   for (int b = 0; b < B; ++b) {
     for (int k = 0; k < d; ++k)
@@ -733,7 +733,7 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
   memset(reports, 0xff, rep_bytes);
   // the fits of all samples side by side in one persistent launch (one critical workgroup each) when that schedule serves
   // this size and the responses are a single column; otherwise one after the other
-  const bool batch = S > 1 && c->ycols == 1 && c->potrf_sched == 3 && c->Npad <= 2048 && c->inverse_inline;
+  const bool batch = S > 1 && c->ycols == 1 && c->potrf_sched == 3 && c->Npad <= B7_PERSIST_NMAX && c->inverse_inline;
   const int n = c->Npad;
   const size_t nn = (size_t)n * n;
   if (batch) {

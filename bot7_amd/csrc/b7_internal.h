@@ -12,6 +12,7 @@
 // Tile constants.  Every matrix dimension that a GEMM-class kernel sees is padded to these.
 constexpr int B7_NPAD = 128;  // observations padded to a multiple of this (post kernel's n-tile)
 constexpr int B7_PANEL = 64;  // Cholesky panel width / small-GEMM tile
+constexpr int B7_PERSIST_NMAX = 4096;  // largest padded N of the persistent Cholesky (64 panels: flag block, the vector job's LDS)
 constexpr int B7_MROWS = 256; // chunk rows are multiples of this (largest candidates-per-block of any post variant)
 constexpr int B7_MAX_D = 96;  // LDS budget of the covariance kernel: (64 + 2*32) rows x (dpad+1) doubles at dpad = 96
 
@@ -23,7 +24,7 @@ static inline int b7_dpad_class(int d) {
 // Device result block of a fit: int info[4] | double nll_terms[1 + 256] | the persistent schedule's hand-off flags (up to
 // nb = 32 panels), so that ONE memset ahead of a persistent launch zeroes info and flags together.
 constexpr size_t B7_INFO_HEAD_BYTES = 16 + sizeof(double) * 257 + 8;                       // 2080: a multiple of 16
-constexpr size_t B7_PERSIST_FLAG_WORDS_MAX = 16 + 2 * 32 * 32 + 2 * 32;                    // FLAG_HDR + 2 nb^2 + 2 nb
+constexpr size_t B7_PERSIST_FLAG_WORDS_MAX = 16 + 2 * 64 * 64 + 2 * 64;                    // FLAG_HDR + 2 nb^2 + 2 nb, nb <= 64
 constexpr size_t B7_INFO_BYTES = B7_INFO_HEAD_BYTES + 4 * B7_PERSIST_FLAG_WORDS_MAX;
 
 struct DevBuf {
@@ -99,7 +100,7 @@ struct b7_ctx {
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
   int potrf_sched = 3;   // 1: one panel at a time (near update fused into the panel solve, far update riding on the
                          // next diagonal-block launch) for Npad <= 4096, 2: always; 0: panel groups with separate
-                         // update launches; 3: ONE persistent launch for Npad <= 2048, else as 1 (B7_POTRF_SCHED)
+                         // update launches; 3: ONE persistent launch for Npad <= 4096, else as 1 (B7_POTRF_SCHED)
   int syrk_small = 1;    // whole-K single-stage kernel for trailing updates with <= 256 tiles (B7_SYRK_SMALL)
   int potrf_defer = 1;   // far part of each trailing update rides on the next diagonal-block launch (B7_POTRF_DEFER)
   int potrf_group = 2;   // panels per bulk trailing update of the Cholesky (B7_POTRF_GROUP overrides); A/B at
@@ -219,7 +220,7 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
 // potrf.hip
 int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I -> L, dinv, info (+ Linv, using W)
 int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
-int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse);  // the same in one persistent launch (Npad <= 2048)
+int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse);  // the same in one persistent launch (Npad <= 4096)
 int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv, unsigned *flags, int *info,
                      const double *resid, double *terms, const double *unused);
 int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned *flags, int *info, const double *resid,

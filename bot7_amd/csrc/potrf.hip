@@ -556,7 +556,7 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
 // own -- the factorisation is a chain of small dependent kernels that leaves most CUs idle.  Needs c->Linv and
 // c->W (n x n each).  Without it (b7_chol) only L and dinv are produced and launch_trtri is the way to inv(L).
 int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
-  if (c->potrf_sched == 3 && c->Npad <= 2048 && c->inverse_inline) return launch_potrf_persist(c, extra, with_inverse);
+  if (c->potrf_sched == 3 && c->Npad <= B7_PERSIST_NMAX && c->inverse_inline) return launch_potrf_persist(c, extra, with_inverse);
   PhaseScope ps(c, "potrf");
   const int n = c->Npad, nb = n / NB;
   double *L = (double *)c->L.p;

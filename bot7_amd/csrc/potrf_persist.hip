@@ -1,4 +1,4 @@
-// Blocked Cholesky + explicit inverse as ONE persistent launch with point-to-point hand-offs (Npad <= 2048).
+// Blocked Cholesky + explicit inverse as ONE persistent launch with point-to-point hand-offs (Npad <= 4096).
 //
 // Same arithmetic as the per-panel launch schedule of potrf.hip, element for element (utils/math.lua:165 torch.potrf +
 // the inline inverse): every 64x64 tile (I, J) of the lower triangle is
@@ -832,6 +832,7 @@ static int persist_jobs(b7_ctx *c, int nb, int mode, const int4 **jobs_dev, int 
     // the queue: sorted by the panel at whose end a job can finish; every dependency of a job is produced by workgroup 0
     // or sits earlier in this order
     std::vector<HostJob> jobs;
+    const double lead = nb <= 32 ? 0.045 : 1.4 / (nb - 1);
     for (int J = 0; J < nb; ++J)
       for (int I = J + 2; I < nb; ++I) jobs.push_back({JOB_TILE, I, J, J + 0.001 * (I - J)});
     for (int p = 2; p < nb; ++p) jobs.push_back({JOB_PRE_SUB, p, p - 1, (p - 1) - 0.6});
@@ -839,9 +840,9 @@ static int persist_jobs(b7_ctx *c, int nb, int mode, const int4 **jobs_dev, int 
     if (mode == 1) {
       for (int p = 1; p < nb; ++p)
         // a tile of row p with many products (small j) is popped up to ~1.4 panels ahead of the light ones: popped late
-        // it would still be catching up on its p - j products when the factorisation is over.  0.045 (p - j) < 1.5 keeps
-        // every L[p][t], t < p (key < p - 1 + 0.04) ahead of it in the queue
-        for (int j = 0; j < p; ++j) jobs.push_back({JOB_INV, p, j, p + 0.5 - 0.045 * (p - j)});
+        // it would still be catching up on its p - j products when the factorisation is over.  lead (p - j) < 1.5 keeps
+        // every L[p][t], t < p (key < p - 1 + 0.001 nb) ahead of it in the queue: 0.045 up to 32 panels, less beyond
+        for (int j = 0; j < p; ++j) jobs.push_back({JOB_INV, p, j, p + 0.5 - lead * (p - j)});
       for (int p = 0; p < nb; ++p) jobs.push_back({JOB_INV_DIAG, p, p, p + 0.9});
     }
     if (mode == 2) {
@@ -888,12 +889,12 @@ static int persist_launch(b7_ctx *c, PArgs a, int B, int mode, int helpers) {
   return B7_OK;
 }
 
-// K + extra*I -> L, dinv, info (+ Linv) in one persistent launch.  The caller has checked Npad <= 2048.
+// K + extra*I -> L, dinv, info (+ Linv) in one persistent launch.  The caller has checked Npad <= B7_PERSIST_NMAX.
 int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse) {
   PhaseScope ps(c, "potrf");
   const int n = c->Npad, nb = n / NB, mode = with_inverse ? 1 : 0;
   c->linv_done = false;
-  static_assert(FLAG_HDR + 2 * 32 * 32 + 2 * 32 == B7_PERSIST_FLAG_WORDS_MAX, "flag block of the largest persistent shape");
+  static_assert(FLAG_HDR + 2 * 64 * 64 + 2 * 64 == B7_PERSIST_FLAG_WORDS_MAX && B7_PERSIST_NMAX == 64 * NB, "flag block of the largest persistent shape");
   B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
   PArgs a = {};
   a.fault_panel = c->persist_fault;

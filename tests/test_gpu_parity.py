@@ -1457,9 +1457,9 @@ def _aborts(c):
 
 
 @pytest.mark.parametrize("N,d,cols", [(2, 3, 1), (64, 6, 1), (100, 6, 1), (129, 6, 1), (256, 6, 7), (700, 32, 1),
-                                      (1024, 32, 1), (1500, 6, 1), (2048, 32, 1)])
+                                      (1024, 32, 1), (1500, 6, 1), (2048, 32, 1), (2100, 6, 1), (3000, 6, 1), (4096, 32, 1)])
 def test_persistent_cholesky_is_bit_identical_to_the_launch_schedule(orc, monkeypatch, N, d, cols):
-    """One persistent launch with flag hand-offs (default up to Npad = 2048) against two launches per panel: L, inv(L),
+    """One persistent launch with flag hand-offs (default up to Npad = 4096) against two launches per panel: L, inv(L),
     alpha and the likelihood must agree bit for bit -- only the schedule differs."""
     launch, persist = _two_schedules(monkeypatch)
     try:
@@ -1664,7 +1664,9 @@ def test_persistent_cholesky_cannot_deadlock_with_few_helpers(orc, monkeypatch, 
     launch, persist = _two_schedules(monkeypatch)
     monkeypatch.delenv("B7_PERSIST_HELPERS")
     try:
-        for N, d, obj in ((300, 6, B.hartmann6), (1100, 6, B.hartmann6)):
+        for N, d, obj in ((300, 6, B.hartmann6), (1100, 6, B.hartmann6), (2500, 6, B.hartmann6)):
+            if N > 2000 and helpers == 1:
+                continue                                  # 40 panels through one helper: minutes, and the order is the same
             X_obs, Y, _, hyp = make_problem(None, orc, d, N, 64, obj)
             out = []
             for c in (launch, persist):
