@@ -54,7 +54,8 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 constexpr int FLAG_HDR = 16;                 // words: [0] queue head, [1] abort code, rest padding
 constexpr unsigned SPIN_LIMIT = 1u << 21;    // polls before a waiter gives up (>= 0.5 s)
 constexpr int PERSIST_LDS_BYTES = (4 * NB * DLD + 32 * TLD) * 8;  // A, X, T, S1, S2 of the critical workgroup: 141 KiB
-static_assert(PERSIST_LDS_BYTES >= 2 * GT::STAGE_DOUBLES * 4 && PERSIST_LDS_BYTES > 80 * 1024, "one workgroup per CU");
+static_assert(PERSIST_LDS_BYTES >= 2 * GT::STAGE_DOUBLES * 8 && PERSIST_LDS_BYTES > 80 * 1024,
+              "two update stages of a tile job; one workgroup per CU");
 
 enum JobType { JOB_TILE = 0, JOB_PRE_SUB = 1, JOB_PRE_DIAG = 2, JOB_INV = 3, JOB_INV_DIAG = 4, JOB_ZERO = 5, JOB_VEC = 6 };
 
@@ -127,6 +128,19 @@ __device__ __forceinline__ bool wg_wait2(unsigned *f0, unsigned *f1, const Flags
       }
     }
     if (threadIdx.x == 0) sh_ok[slot] = ok;
+  }
+  __syncthreads();
+  return sh_ok[slot] != 0;
+}
+// One look at two flags, no waiting: true when both are up.  Ends with a barrier, like wg_wait2.
+__device__ __forceinline__ bool wg_test2(unsigned *f0, unsigned *f1, int *sh_ok, int &turn) {
+  const int slot = turn & 1;
+  turn += 1;
+  if (threadIdx.x < 64) {
+    unsigned *mine = (threadIdx.x & 1) ? f1 : f0;
+    const bool set = threadIdx.x > 1 || ld_flag(mine) != 0u;
+    const bool all = __all(set);
+    if (threadIdx.x == 0) sh_ok[slot] = all ? 1 : 0;
   }
   __syncthreads();
   return sh_ok[slot] != 0;
@@ -468,22 +482,6 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
 #undef PST
 }
 
-// ---- helper jobs ------------------------------------------------------------------------------------------------------
-// C_{q+1} = C_q - L_Iq L_Jq': both tiles to LDS, one 64-deep chain per accumulator from zero, subtract.
-__device__ __forceinline__ void apply_update(d4_t (&C)[2][2], const double *Lq_I, const double *Lq_J, int n, double *sm) {
-  GT::Regs r;
-  tile_load_sc1(r.a, Lq_I, n);
-  tile_load_sc1(r.b, Lq_J, n);
-  GT::store_lds(r, sm);
-  __syncthreads();
-  d4_t P[2][2] = {};
-  GT::compute_stage(sm, P);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) C[i][j] = C[i][j] - P[i][j];
-}
 
 __device__ __forceinline__ void acc_to_lds(const d4_t (&C)[2][2], double *img, int stride) {
 #pragma unroll
@@ -515,12 +513,45 @@ __device__ bool tile_job(const PArgs &a, const Flags &F, int type, int I, int J,
   }
   const int nupd = (type == JOB_PRE_DIAG) ? J - 1 : J;  // the critical workgroup applies panel J-1 to its own diagonal tile
   unsigned long long busy = 0;
-  for (int q = 0; q < nupd; ++q) {
-    if (!wg_wait2(F.ready(I, q), F.ready(J, q), F, a.info, sh_ok, turn, 1000 + I * 64 + q)) return false;
-    const unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    apply_update(C, a.L + ((int64_t)I * NB) * n + (int64_t)q * NB, a.L + ((int64_t)J * NB) * n + (int64_t)q * NB, n, sm);
-    if (a.stamps) busy += __builtin_amdgcn_s_memtime() - t0;
+  // C_{q+1} = C_q - L_Iq L_Jq', q ascending.  The two tiles of update q + 1 are requested BEFORE update q is computed whenever
+  // their flags are already up (one look, no waiting: away from the front of the factorisation they always are), into the
+  // other half of the staging area: the load latency (~1 us of a 2.9 us update) hides under the 64 MFMAs per wave.  At
+  // the front the old order remains: wait, load, compute.  Same products, same subtractions, same order.
+  GT::Regs r;
+  const double *Li = a.L + ((int64_t)I * NB) * n, *Lj = a.L + ((int64_t)J * NB) * n;
+  if (nupd > 0) {
+    if (!wg_wait2(F.ready(I, 0), F.ready(J, 0), F, a.info, sh_ok, turn, 1000 + I * 64)) return false;
+    tile_load_sc1(r.a, Li, n);
+    tile_load_sc1(r.b, Lj, n);
   }
+  for (int q = 0; q < nupd; ++q) {
+    const unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    double *st = sm + (q & 1) * GT::STAGE_DOUBLES;  // rewritten at q + 2, behind the barrier of q + 1
+    GT::store_lds(r, st);
+    bool ahead = false;
+    if (q + 1 < nupd) {
+      ahead = wg_test2(F.ready(I, q + 1), F.ready(J, q + 1), sh_ok, turn);  // its barrier also publishes the stage
+      if (ahead) {
+        tile_load_sc1(r.a, Li + (int64_t)(q + 1) * NB, n);
+        tile_load_sc1(r.b, Lj + (int64_t)(q + 1) * NB, n);
+      }
+    } else {
+      __syncthreads();
+    }
+    d4_t P[2][2] = {};
+    GT::compute_stage(st, P);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) C[i][j] = C[i][j] - P[i][j];
+    if (a.stamps) busy += __builtin_amdgcn_s_memtime() - t0;
+    if (q + 1 < nupd && !ahead) {
+      if (!wg_wait2(F.ready(I, q + 1), F.ready(J, q + 1), F, a.info, sh_ok, turn, 1000 + I * 64 + q + 1)) return false;
+      tile_load_sc1(r.a, Li + (int64_t)(q + 1) * NB, n);
+      tile_load_sc1(r.b, Lj + (int64_t)(q + 1) * NB, n);
+    }
+  }
+  __syncthreads();  // everybody is done with the staging area: the epilogue below reuses it
   if (a.stamps && tid == 0) {
     a.stamps[a.nb * 8 + jid * 4 + 2] = busy;
     a.stamps[a.nb * 8 + jid * 4 + 3] = (unsigned long long)nupd;
