@@ -604,30 +604,50 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
   const int n = a.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   d4_t tot[2][2] = {}, cur[2][2] = {};
-  for (int t = j; t < p; ++t) {
-    if (!wg_wait2(F.ready(p, t), t == j ? F.ready(j, j) : F.iready(t, j), F, a.info, sh_ok, turn, 10000 + p * 64 + t)) return false;
+  // Products L[p][t] * inv(L)[t][j], t = j .. p-1, in 128-deep chunks summed in ascending order.  As in tile_job, the pair of
+  // tiles of step t + 1 is requested before step t is computed whenever its flags are already up (one look, no waiting),
+  // into the other half of the staging area.
+  GN::Regs r;
+  auto flags_of = [&](int t, unsigned *&f0, unsigned *&f1) {
+    f0 = F.ready(p, t);
+    f1 = t == j ? F.ready(j, j) : F.iready(t, j);
+  };
+  auto request = [&](int t) {
     const double *Lpt = a.L + ((int64_t)p * NB) * n + (int64_t)t * NB;
     // rows [64 t, 64 t + 64) x columns [64 j, ..) of inv(L); the diagonal tile is inv(L_jj) itself
     const double *Btile = (t == j) ? a.dinv + (int64_t)j * NB * NB : a.Linv + ((int64_t)t * NB) * n + (int64_t)j * NB;
     const int ldb = (t == j) ? NB : n;
     const __amdgpu_buffer_rsrc_t ra = tile_rsrc(Lpt), rb = tile_rsrc(Btile);
-    {  // the whole 64-deep tile pair in one LDS stage: the same k-ascending chain as two 32-deep stages, one round trip
-      GN::Regs r;
 #pragma unroll
-      for (int i = 0; i < GN::A_PER_T; ++i) {
-        const int c = tid + i * 256, row = c / 32, kc = c % 32;
-        r.a[i] = ld16_sc1(ra, (row * n + 2 * kc) * 8);
-      }
+    for (int i = 0; i < GN::A_PER_T; ++i) {
+      const int c = tid + i * 256, row = c / 32, kc = c % 32;
+      r.a[i] = ld16_sc1(ra, (row * n + 2 * kc) * 8);
+    }
 #pragma unroll
-      for (int i = 0; i < GN::B_PER_T; ++i) {
-        const int c = tid + i * 256, kr = c / 32, nc = c % 32;
-        r.b[i] = ld16_sc1(rb, (kr * ldb + 2 * nc) * 8);
-      }
-      GN::store_lds(r, sm);
-      __syncthreads();
-      GN::compute_stage(sm, cur);  // the chain runs on through a chunk's second tile
+    for (int i = 0; i < GN::B_PER_T; ++i) {
+      const int c = tid + i * 256, kr = c / 32, nc = c % 32;
+      r.b[i] = ld16_sc1(rb, (kr * ldb + 2 * nc) * 8);
+    }
+  };
+  if (j < p) {
+    unsigned *f0, *f1;
+    flags_of(j, f0, f1);
+    if (!wg_wait2(f0, f1, F, a.info, sh_ok, turn, 10000 + p * 64 + j)) return false;
+    request(j);
+  }
+  for (int t = j; t < p; ++t) {
+    double *st = sm + ((t - j) & 1) * GN::STAGE_DOUBLES;  // rewritten two steps on, behind the barrier of the next step
+    GN::store_lds(r, st);  // the whole 64-deep tile pair in one LDS stage: the same k-ascending chain, one round trip
+    bool ahead = false;
+    unsigned *f0 = nullptr, *f1 = nullptr;
+    if (t + 1 < p) {
+      flags_of(t + 1, f0, f1);
+      ahead = wg_test2(f0, f1, sh_ok, turn);  // its barrier also publishes the stage
+      if (ahead) request(t + 1);
+    } else {
       __syncthreads();
     }
+    GN::compute_stage(st, cur);  // the chain runs on through a chunk's second tile
     if ((t & 1) == 1 || t == p - 1) {  // end of the 128-deep chunk t / 2: partials are summed in ascending chunk order
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -637,7 +657,12 @@ __device__ bool inv_job(const PArgs &a, const Flags &F, int p, int j, double *sm
           cur[i][jj] = d4_t{0.0, 0.0, 0.0, 0.0};
         }
     }
+    if (t + 1 < p && !ahead) {
+      if (!wg_wait2(f0, f1, F, a.info, sh_ok, turn, 10000 + p * 64 + t + 1)) return false;
+      request(t + 1);
+    }
   }
+  __syncthreads();  // everybody is done with the staging area: the epilogue below reuses it
   if (!wg_wait(F.ready(p, p), F, a.info, sh_ok, turn, 30000 + p)) return false;
   constexpr int SLD = 65;  // odd stride: the B-operand reads (k = lane >> 4, n = lane & 15) stay conflict-free
   double *Dn = sm, *Ts = sm + NB * DLD;
