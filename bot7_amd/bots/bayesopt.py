@@ -54,13 +54,14 @@ class bayesopt(abstract):
         model.sample_hypers(X_obs, Y_obs)                         # :68 (burn-in call)
         nSamples = self.config["bot"]["nSamples"]
         spec = getattr(self.score, "device_spec", None)
-        if not want_scores and spec is not None and self.config["bot"].get("fused", True) \
-                and hasattr(model, "stage"):       # (the driver never hands pending points to the score, :66,76)
+        if spec is not None and self.config["bot"].get("fused", True) and hasattr(model, "stage"):
+            # (the driver never hands pending points to the score, :66,76)
             hyps = [model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True)) for _ in range(nSamples)]
             model.stage(X_obs, Y_obs, X_hid)                      # data + grid resident (uploads only what changed)
             val, idx = ctx.eval_nominate(hyps, **spec(Y_obs))     # :73-79 + :96 in one call
-            self.last_scores = None
-            return None, val, idx
+            scores = ctx.score_finish(1.0, download=True)[2] if want_scores else None   # the accumulator holds score / S
+            self.last_scores = scores
+            return scores, val, idx
         first = True
         for _ in range(nSamples):                                 # :73-78
             hyp = model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True))
