@@ -20,9 +20,14 @@ ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove", "b7_grid_remove_rows",
+    "b7_grid_colrange", "b7_grid_apply_onesided",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_predict_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
     "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global", "b7_eval_nominate",
+    "b7_nominate_commit", "b7_shard_commit_rule", "b7_exchange_info",
+    "b7_group_create", "b7_group_destroy", "b7_group_last_error", "b7_group_info", "b7_group_ctx", "b7_group_set_workspace", "b7_group_gp_set_opts",
+    "b7_group_grid_sobol", "b7_group_grid_random", "b7_group_grid_onesided", "b7_group_grid_upload", "b7_group_grid_shape", "b7_group_grid_download",
+    "b7_group_grid_remove_rows", "b7_group_gp_set_data", "b7_group_eval_nominate", "b7_group_nominate_commit",
     "b7_ei_compute", "b7_cb_compute", "b7_argmax",
     "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
 ]
@@ -129,6 +134,28 @@ def load():
         "b7_score_finish_global": (i32, [vp, dbl, i64, C.POINTER(dbl), C.POINTER(i64)]),
         "b7_eval_nominate": (i32, [vp, i32, C.POINTER(Hyp), C.POINTER(ScoreSpec), i64, C.POINTER(dbl), C.POINTER(i64),
                                    vp, vp]),
+        "b7_grid_colrange": (i32, [vp, vp, vp]),
+        "b7_grid_apply_onesided": (i32, [vp, vp, vp, vp]),
+        "b7_nominate_commit": (i32, [vp, i64, C.POINTER(i64), vp]),
+        "b7_shard_commit_rule": (i32, [i64, i64, i64, C.POINTER(i64), C.POINTER(i64)]),
+        "b7_exchange_info": (i32, [vp, C.POINTER(i32), vp, C.POINTER(i64), C.POINTER(i32), vp]),
+        "b7_group_create": (i32, [C.POINTER(vp), i32, vp]),
+        "b7_group_destroy": (None, [vp]),
+        "b7_group_last_error": (C.c_char_p, [vp]),
+        "b7_group_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "b7_group_ctx": (vp, [vp, i32]),
+        "b7_group_set_workspace": (i32, [vp, i64]),
+        "b7_group_gp_set_opts": (i32, [vp, C.POINTER(GpOpts)]),
+        "b7_group_grid_sobol": (i32, [vp, i64, i32, i64, vp, vp]),
+        "b7_group_grid_random": (i32, [vp, i64, i32, C.c_uint64, vp, vp]),
+        "b7_group_grid_onesided": (i32, [vp, vp, vp]),
+        "b7_group_grid_upload": (i32, [vp, vp, i64, i32]),
+        "b7_group_grid_shape": (i32, [vp, C.POINTER(i64), C.POINTER(i32), vp]),
+        "b7_group_grid_download": (i32, [vp, i64, i64, vp]),
+        "b7_group_grid_remove_rows": (i32, [vp, vp, i64, vp]),
+        "b7_group_gp_set_data": (i32, [vp, vp, vp, i32, i32, i32]),
+        "b7_group_eval_nominate": (i32, [vp, i32, C.POINTER(Hyp), C.POINTER(ScoreSpec), C.POINTER(dbl), C.POINTER(i64), vp, vp]),
+        "b7_group_nominate_commit": (i32, [vp, i64, vp]),
         "b7_ei_compute": (i32, [vp, vp, vp, vp, dbl, i64, i32, vp]),
         "b7_cb_compute": (i32, [vp, vp, vp, dbl, i32, dbl, i64, i32, vp]),
         "b7_argmax": (i32, [vp, vp, i64, C.POINTER(dbl), C.POINTER(i64)]),
@@ -161,20 +188,24 @@ def _ptr(a):
 class Context(object):
     """One GPU's worth of state: the resident candidate grid, the current GP fit, the score accumulator."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _borrowed=None):
         self._L = load()
-        h = C.c_void_p()
-        rc = self._L.b7_create(C.byref(h), int(device_id))
-        if rc != B7_OK:
-            raise Bot7HipError(rc, (self._L.b7_last_error(None) or b"").decode())
-        self._h = h
+        if _borrowed is not None:   # a member of a Group: the handle belongs to the group
+            self._h, self._owned = C.c_void_p(_borrowed), False
+        else:
+            h = C.c_void_p()
+            rc = self._L.b7_create(C.byref(h), int(device_id))
+            if rc != B7_OK:
+                raise Bot7HipError(rc, (self._L.b7_last_error(None) or b"").decode())
+            self._h, self._owned = h, True
         self.device_id = int(device_id)
         self.grid_version = 0  # bumped whenever the resident grid changes (DeviceGrid views compare against it)
         self.fit_token = 0     # bumped by every call that replaces the fit (models check it before gp_append)
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.b7_destroy(self._h)
+            if self._owned:
+                self._L.b7_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -205,10 +236,10 @@ class Context(object):
     def _minmax(mins, maxes, dims):
         if mins is None and maxes is None:
             return None, None
-        if mins is None or maxes is None:
-            raise Bot7HipError(-5, "give both mins and maxes or neither")
-        mn, mx = _f64(mins).ravel(), _f64(maxes).ravel()
-        if mn.size != dims or mx.size != dims:
+        # one of the two alone selects the one-sided maps of grids/sobol.lua:82-85
+        mn = None if mins is None else _f64(mins).ravel()
+        mx = None if maxes is None else _f64(maxes).ravel()
+        if (mn is not None and mn.size != dims) or (mx is not None and mx.size != dims):
             raise Bot7HipError(-1, "mins/maxes must have `dims` entries")
         return mn, mx
 
@@ -261,6 +292,20 @@ class Context(object):
         self._ck(self._L.b7_grid_remove_rows(self._h, _ptr(idx), idx.size, _ptr(rows)))
         self.grid_version += 1
         return rows
+
+    def grid_colrange(self):
+        """grid:min(1), grid:max(1) of the resident grid."""
+        _, d = self.grid_shape()
+        lo, hi = np.empty(d), np.empty(d)
+        self._ck(self._L.b7_grid_colrange(self._h, _ptr(lo), _ptr(hi)))
+        return lo, hi
+
+    def grid_apply_onesided(self, mins=None, maxes=None, col_ext=None):
+        mn = None if mins is None else _f64(mins).ravel()
+        mx = None if maxes is None else _f64(maxes).ravel()
+        ext = _f64(col_ext).ravel()
+        self._ck(self._L.b7_grid_apply_onesided(self._h, _ptr(mn), _ptr(mx), _ptr(ext)))
+        self.grid_version += 1
 
     # ---- model
     def gp_set_opts(self, **kw):
@@ -517,10 +562,25 @@ class Context(object):
                                                 C.byref(i)))
         return v.value, i.value
 
-    def eval_nominate(self, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0,
-                      global_row_offset=0, want_report=False):
-        """bayesopt:eval + nominate in one call: hyps is a sequence of (lenscale_sq, amp, noise, mean) or dicts
-        with those keys; score "ei" (needs fmin) or "cb".  Returns (value, 1-based global index[, report])."""
+    def nominate_commit(self, idx1_global, global_row_offset=0):
+        """bots/abstract.lua:118 on a sharded candidate set -> (nominee's row, this rank's new row offset)."""
+        _, d = self.grid_shape()
+        row, off = np.empty(d, dtype=np.float64), C.c_int64(int(global_row_offset))
+        self._ck(self._L.b7_nominate_commit(self._h, int(idx1_global), C.byref(off), _ptr(row)))
+        self.grid_version += 1
+        return row, off.value
+
+    def exchange_info(self):
+        """The last exchange as this rank saw it: rows per rank, winner index / rank / row."""
+        w, wi, wr = C.c_int(), C.c_int64(), C.c_int()
+        rows, row = np.zeros(64, dtype=np.int64), np.zeros(96, dtype=np.float64)
+        self._ck(self._L.b7_exchange_info(self._h, C.byref(w), _ptr(rows), C.byref(wi), C.byref(wr), _ptr(row)))
+        _, d = self.grid_shape()
+        return {"world": w.value, "rows": rows[:w.value].copy(), "winner_idx1": wi.value, "winner_rank": wr.value,
+                "winner_row": row[:d].copy()}
+
+    @staticmethod
+    def _pack_hyps(hyps, d):
         S = len(hyps)
         arr = (Hyp * S)()
         keep = []
@@ -528,22 +588,32 @@ class Context(object):
             if isinstance(h, dict):
                 h = (h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
             ls = _f64(h[0]).ravel()
-            if ls.size != getattr(self, "_data_d", -1):
+            if ls.size != d:
                 raise Bot7HipError(-1, "lenscale_sq must have d entries (call gp_set_data first)")
             keep.append(ls)
             arr[s] = Hyp(ls.ctypes.data_as(C.POINTER(C.c_double)), float(h[1]), float(h[2]), float(h[3]))
+        return arr, keep
+
+    @staticmethod
+    def _pack_spec(score, fmin, tradeoff, upper, sign):
         if score == "ei":
             if fmin is None:
                 raise Bot7HipError(-1, "EI needs fmin")
             fm = _f64(fmin).ravel()
-            spec = ScoreSpec(SCORE_EI, 0.0 if tradeoff is None else float(tradeoff), 0, 0.0,
-                             fm.ctypes.data_as(C.POINTER(C.c_double)))
-        elif score == "cb":
-            fm = None
-            spec = ScoreSpec(SCORE_CB, 1.0 if tradeoff is None else float(tradeoff), int(bool(upper)), float(sign),
-                             None)
-        else:
-            raise Bot7HipError(-1, "score must be 'ei' or 'cb'")
+            return ScoreSpec(SCORE_EI, 0.0 if tradeoff is None else float(tradeoff), 0, 0.0,
+                             fm.ctypes.data_as(C.POINTER(C.c_double))), fm
+        if score == "cb":
+            return ScoreSpec(SCORE_CB, 1.0 if tradeoff is None else float(tradeoff), int(bool(upper)), float(sign),
+                             None), None
+        raise Bot7HipError(-1, "score must be 'ei' or 'cb'")
+
+    def eval_nominate(self, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0,
+                      global_row_offset=0, want_report=False):
+        """bayesopt:eval + nominate in one call: hyps is a sequence of (lenscale_sq, amp, noise, mean) or dicts
+        with those keys; score "ei" (needs fmin) or "cb".  Returns (value, 1-based global index[, report])."""
+        S = len(hyps)
+        arr, keep = self._pack_hyps(hyps, getattr(self, "_data_d", -1))
+        spec, fm = self._pack_spec(score, fmin, tradeoff, upper, sign)
         jit = np.zeros(S, dtype=np.float64) if want_report else None
         info = np.zeros(S, dtype=np.int32) if want_report else None
         v, i = C.c_double(), C.c_int64()
@@ -601,6 +671,124 @@ class Context(object):
         ms, n = C.c_double(), C.c_int64()
         self._ck(self._L.b7_profile_get(self._h, phase.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Group(object):
+    """One host process, several GPUs (b7_group_*): a candidate grid sharded over the members, the observations on every
+    member, bayesopt:eval + nominate over the union as one call.  device_ids may repeat (virtual ranks on one device)."""
+
+    def __init__(self, device_ids):
+        self._L = load()
+        ids = np.ascontiguousarray(np.asarray(device_ids, dtype=np.int32).ravel())
+        h = C.c_void_p()
+        rc = self._L.b7_group_create(C.byref(h), ids.size, _ptr(ids))
+        if rc != B7_OK:
+            raise Bot7HipError(rc, (self._L.b7_last_error(None) or b"").decode())
+        self._h, self.n = h, int(ids.size)
+        self.members = [Context(int(ids[r]), _borrowed=self._L.b7_group_ctx(h, r)) for r in range(self.n)]
+        self._data_d = -1
+        self.grid_version = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for m in self.members:
+                m.close()
+            self._L.b7_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != B7_OK:
+            raise Bot7HipError(rc, (self._L.b7_group_last_error(self._h) or b"").decode())
+
+    def info(self):
+        n, r = C.c_int(), C.c_int()
+        self._ck(self._L.b7_group_info(self._h, C.byref(n), C.byref(r)))
+        return {"n": n.value, "uses_rccl": bool(r.value)}
+
+    def set_workspace(self, nbytes):
+        self._ck(self._L.b7_group_set_workspace(self._h, int(nbytes)))
+
+    def grid_sobol(self, size, dims, skip=1, mins=None, maxes=None):
+        mn, mx = Context._minmax(mins, maxes, dims)
+        self._ck(self._L.b7_group_grid_sobol(self._h, int(size), int(dims), int(skip), _ptr(mn), _ptr(mx)))
+        self.grid_version += 1
+
+    def grid_random(self, size, dims, seed=0, mins=None, maxes=None):
+        mn, mx = Context._minmax(mins, maxes, dims)
+        self._ck(self._L.b7_group_grid_random(self._h, int(size), int(dims), int(seed) & (2 ** 64 - 1), _ptr(mn), _ptr(mx)))
+        self.grid_version += 1
+
+    def grid_upload(self, X):
+        X = _f64(X)
+        self._ck(self._L.b7_group_grid_upload(self._h, _ptr(X), X.shape[0], X.shape[1]))
+        self.grid_version += 1
+
+    def grid_shape(self):
+        M, d, off = C.c_int64(), C.c_int(), np.zeros(self.n + 1, dtype=np.int64)
+        self._ck(self._L.b7_group_grid_shape(self._h, C.byref(M), C.byref(d), _ptr(off)))
+        return M.value, d.value, off
+
+    def grid_download(self, row0=0, rows=None):
+        M, d, _ = self.grid_shape()
+        rows = M - row0 if rows is None else rows
+        out = np.empty((rows, d), dtype=np.float64)
+        self._ck(self._L.b7_group_grid_download(self._h, int(row0), int(rows), _ptr(out)))
+        return out
+
+    def grid_remove_rows(self, idx1, want_rows=True):
+        idx = np.ascontiguousarray(np.asarray(idx1, dtype=np.int64).ravel())
+        _, d, _ = self.grid_shape()
+        rows = np.empty((idx.size, d), dtype=np.float64) if want_rows else None
+        self._ck(self._L.b7_group_grid_remove_rows(self._h, _ptr(idx), idx.size, _ptr(rows)))
+        self.grid_version += 1
+        return rows
+
+    def gp_set_data(self, X_obs, Y_obs):
+        X = _f64(X_obs)
+        Y = _f64(Y_obs)
+        if Y.ndim == 1:
+            Y = Y.reshape(-1, 1)
+        self._ck(self._L.b7_group_gp_set_data(self._h, _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1]))
+        self._data_d = X.shape[1]
+        for m in self.members:
+            m._data_d = X.shape[1]
+            m.ycols = Y.shape[1]
+            m.fit_token += 1
+
+    def eval_nominate(self, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0, want_report=False):
+        S = len(hyps)
+        arr, keep = Context._pack_hyps(hyps, self._data_d)
+        spec, fm = Context._pack_spec(score, fmin, tradeoff, upper, sign)
+        jit = np.zeros(S, dtype=np.float64) if want_report else None
+        info = np.zeros(S, dtype=np.int32) if want_report else None
+        v, i = C.c_double(), C.c_int64()
+        self._ck(self._L.b7_group_eval_nominate(self._h, S, arr, C.byref(spec), C.byref(v), C.byref(i), _ptr(jit), _ptr(info)))
+        if want_report:
+            return v.value, i.value, {"jitter": jit, "info": info}
+        return v.value, i.value
+
+    def nominate_commit(self, idx1_global):
+        _, d, _ = self.grid_shape()
+        row = np.empty(d, dtype=np.float64)
+        self._ck(self._L.b7_group_nominate_commit(self._h, int(idx1_global), _ptr(row)))
+        self.grid_version += 1
+        return row
+
+
+def shard_commit_rule(idx1_global, offset, M_local):
+    """The library's bookkeeping rule for a stable deletion on the union of contiguous shards -> (local_idx1, new_offset).
+    Host-only."""
+    loc, off = C.c_int64(), C.c_int64()
+    rc = load().b7_shard_commit_rule(int(idx1_global), int(offset), int(M_local), C.byref(loc), C.byref(off))
+    if rc != B7_OK:
+        raise Bot7HipError(rc, "bad index / offset")
+    return loc.value, off.value
 
 
 COMM_ID_BYTES = 128

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "b7_internal.h"
 
@@ -101,6 +102,33 @@ static void invalidate_predictions(b7_ctx *c) {
   c->predicted = false;
   c->acc_valid = false;
   c->Mfeat = 0;  // DNGO features belong to the grid they were computed from
+  c->win_valid = false;  // so does the winner's row of the last exchange
+}
+
+static int group_guard(b7_ctx *c, const char *who) {
+  if (c->group && !c->group_busy)
+    return b7_fail(c, B7_ERR_STATE, "%s: this context's grid is a shard of a group; use the b7_group_grid_* calls", who);
+  return B7_OK;
+}
+
+// Stable deletion of candidate row local_idx1 (utils/tensor.lua:158-170), enqueued on the context's stream.  With row_out
+// the removed row is copied out first and the stream is synchronised.
+int grid_drop_row(b7_ctx *c, int64_t idx1, double *row_out) {
+  B7_TRY(group_guard(c, "grid_remove"));
+  if (idx1 < 1 || idx1 > c->M)
+    return b7_fail(c, B7_ERR_INVALID, "grid_remove: index %lld outside [1, %lld]", (long long)idx1, (long long)c->M);
+  B7_HIP(c, hipSetDevice(c->device));
+  if (row_out)
+    B7_HIP(c, hipMemcpyAsync(row_out, cur_grid(c) + (idx1 - 1) * c->d, sizeof(double) * c->d, hipMemcpyDeviceToHost,
+                             c->stream));
+  const int other = c->grid_cur ^ 1;
+  B7_TRY(b7_ensure(c, c->grid[other], sizeof(double) * (size_t)c->M * c->d));
+  B7_TRY(launch_remove_row(c, cur_grid(c), (double *)c->grid[other].p, c->M, c->d, idx1 - 1));
+  c->grid_cur = other;
+  c->M -= 1;
+  invalidate_predictions(c);
+  if (row_out) B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
 }
 
 extern "C" {
@@ -182,6 +210,7 @@ void b7_destroy(b7_ctx *c) {
   resolve_phases(c);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pin_eval) (void)hipHostFree(c->pin_eval);
+  if (c->tab_host) (void)hipHostFree(c->tab_host);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
   if (c->ev_fit) (void)hipEventDestroy(c->ev_fit);
@@ -215,6 +244,7 @@ int b7_set_workspace(b7_ctx *c, int64_t bytes) {
 
 // ---- grids ---------------------------------------------------------------------------------------------
 static int grid_alloc(b7_ctx *c, int64_t M, int d) {
+  B7_TRY(group_guard(c, "grid"));
   if (M < 0 || d < 1) return b7_fail(c, B7_ERR_INVALID, "grid: size %lld dims %d", (long long)M, d);
   if (d > B7_MAX_D) return b7_fail(c, B7_ERR_UNSUPPORTED, "grid: dims %d > %d", d, B7_MAX_D);
   B7_HIP(c, hipSetDevice(c->device));
@@ -234,20 +264,36 @@ static int grid_copy_out(b7_ctx *c, double *out_host) {
   return B7_OK;
 }
 
+// grids/sobol.lua:82-85, grids/random.lua:29-32: only one of mins / maxes given.  The shift / scale uses the column minima /
+// maxima of the WHOLE grid: with a communicator the shards' extremes are combined by one all-reduce (min / max of d doubles).
+static int onesided(b7_ctx *c, const double *mins, const double *maxes) {
+  const int d = c->d;
+  std::vector<double> ext(2 * (size_t)d);
+  for (int k = 0; k < d; ++k) ext[k] = INFINITY, ext[d + k] = -INFINITY;  // an empty shard constrains nothing
+  if (c->M > 0) B7_TRY(b7_grid_colrange(c, ext.data(), ext.data() + d));
+  double *use = mins ? ext.data() : ext.data() + d;
+  if (c->comm && c->comm_world > 1) {
+    for (int k0 = 0; k0 < d; k0 += 128)
+      B7_TRY(b7_comm_allreduce_f64(c, use + k0, std::min(128, d - k0), mins ? B7_COMM_MIN : B7_COMM_MAX));
+  }
+  if (c->M == 0) return B7_OK;
+  return b7_grid_apply_onesided(c, mins, maxes, use);
+}
+
 int b7_grid_sobol(b7_ctx *c, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
                   double *out_host) {
   if (!c) return B7_ERR_INVALID;
   if (size < 0 || skip < 0) return b7_fail(c, B7_ERR_INVALID, "sobol: size %lld skip %lld", (long long)size, (long long)skip);
   if (dims < 1 || dims >= 40)  // assert(C.dims and C.dims < C.max_dims), grids/sobol.lua:36
     return b7_fail(c, B7_ERR_RANGE, "sobol: dims %d not in [1, 39] (grids/sobol.lua:36)", dims);
-  if ((mins == nullptr) != (maxes == nullptr))
-    return b7_fail(c, B7_ERR_UNSUPPORTED, "sobol: give both mins and maxes or neither");
   // "Too many calls": lo0(seed) must stay <= 30 (grids/sobol.lua:317-324) -> seed <= 2^30 - 2
   if (size > 0 && size + skip - 1 > ((int64_t)1 << 30) - 2)
     return b7_fail(c, B7_ERR_RANGE, "sobol: point index %lld beyond 2^30-2 (grids/sobol.lua:317-324)",
                    (long long)(size + skip - 1));
+  const bool both = mins && maxes;
   B7_TRY(grid_alloc(c, size, dims));
-  B7_TRY(launch_sobol(c, cur_grid(c), size, dims, skip, mins, maxes));
+  B7_TRY(launch_sobol(c, cur_grid(c), size, dims, skip, both ? mins : nullptr, both ? maxes : nullptr));
+  if (!both && (mins || maxes)) B7_TRY(onesided(c, mins, maxes));
   return grid_copy_out(c, out_host);
 }
 
@@ -255,11 +301,46 @@ int b7_grid_random(b7_ctx *c, int64_t size, int dims, uint64_t seed, int64_t row
                    const double *maxes, double *out_host) {
   if (!c) return B7_ERR_INVALID;
   if (size < 0 || row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "random grid: size/offset negative");
-  if ((mins == nullptr) != (maxes == nullptr))
-    return b7_fail(c, B7_ERR_UNSUPPORTED, "random grid: give both mins and maxes or neither");
+  const bool both = mins && maxes;
   B7_TRY(grid_alloc(c, size, dims));
-  B7_TRY(launch_random_grid(c, cur_grid(c), size, dims, seed, row_offset, mins, maxes));
+  B7_TRY(launch_random_grid(c, cur_grid(c), size, dims, seed, row_offset, both ? mins : nullptr, both ? maxes : nullptr));
+  if (!both && (mins || maxes)) B7_TRY(onesided(c, mins, maxes));
   return grid_copy_out(c, out_host);
+}
+
+int b7_grid_colrange(b7_ctx *c, double *col_min, double *col_max) {
+  if (!c) return B7_ERR_INVALID;
+  if (c->M <= 0) return b7_fail(c, B7_ERR_STATE, "grid_colrange: no candidate grid on this context");
+  B7_HIP(c, hipSetDevice(c->device));
+  const int d = c->d;
+  double *out_dev = (double *)((char *)c->scratch.p + 8192 + 4096);  // 2 x 96 doubles, clear of the Sobol table
+  B7_TRY(launch_colrange(c, cur_grid(c), c->M, d, out_dev));
+  std::vector<double> h(2 * (size_t)d);
+  B7_HIP(c, hipMemcpyAsync(h.data(), out_dev, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (col_min) memcpy(col_min, h.data(), sizeof(double) * d);
+  if (col_max) memcpy(col_max, h.data() + d, sizeof(double) * d);
+  return B7_OK;
+}
+
+int b7_grid_apply_onesided(b7_ctx *c, const double *mins, const double *maxes, const double *col_ext) {
+  if (!c) return B7_ERR_INVALID;
+  if ((mins != nullptr) == (maxes != nullptr) || !col_ext)
+    return b7_fail(c, B7_ERR_INVALID, "grid_apply_onesided: exactly one of mins / maxes, and the column extremes");
+  B7_TRY(group_guard(c, "grid_apply_onesided"));
+  B7_HIP(c, hipSetDevice(c->device));
+  const int d = c->d;
+  // torch.add(mins, grid:min(1)[1]) (grids/sobol.lua:83) / torch.cdiv(maxes, grid:max(1)[1]) (:85): one rounded operation per
+  // column, here; then one per element on the device
+  double *stage = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 8192);  // the lengthscale staging slot
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < d; ++k) stage[k] = mins ? mins[k] + col_ext[k] : maxes[k] / col_ext[k];
+  double *v_dev = (double *)((char *)c->scratch.p + 8192 + 4096);
+  B7_HIP(c, hipMemcpyAsync(v_dev, stage, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_col_affine(c, cur_grid(c), c->M, d, v_dev, maxes != nullptr));
+  invalidate_predictions(c);
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  return B7_OK;
 }
 
 int b7_grid_upload(b7_ctx *c, const double *X, int64_t M, int d) {
@@ -293,18 +374,7 @@ int b7_grid_shape(b7_ctx *c, int64_t *M, int *d) {
 
 int b7_grid_remove(b7_ctx *c, int64_t idx1, double *row_out) {
   if (!c) return B7_ERR_INVALID;
-  if (idx1 < 1 || idx1 > c->M)
-    return b7_fail(c, B7_ERR_INVALID, "grid_remove: index %lld outside [1, %lld]", (long long)idx1, (long long)c->M);
-  B7_HIP(c, hipSetDevice(c->device));
-  if (row_out)
-    B7_HIP(c, hipMemcpyAsync(row_out, cur_grid(c) + (idx1 - 1) * c->d, sizeof(double) * c->d, hipMemcpyDeviceToHost,
-                             c->stream));
-  const int other = c->grid_cur ^ 1;
-  B7_TRY(b7_ensure(c, c->grid[other], sizeof(double) * (size_t)c->M * c->d));
-  B7_TRY(launch_remove_row(c, cur_grid(c), (double *)c->grid[other].p, c->M, c->d, idx1 - 1));
-  c->grid_cur = other;
-  c->M -= 1;
-  invalidate_predictions(c);
+  B7_TRY(grid_drop_row(c, idx1, row_out));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
 }
@@ -312,6 +382,7 @@ int b7_grid_remove(b7_ctx *c, int64_t idx1, double *row_out) {
 int b7_grid_remove_rows(b7_ctx *c, const int64_t *idx1, int64_t n, double *rows_out) {
   if (!c) return B7_ERR_INVALID;
   if (n < 0 || (n > 0 && !idx1)) return b7_fail(c, B7_ERR_INVALID, "grid_remove_rows: bad index list");
+  B7_TRY(group_guard(c, "grid_remove_rows"));
   if (n == 0) return B7_OK;
   for (int64_t i = 0; i < n; ++i)
     if (idx1[i] < 1 || idx1[i] > c->M)
@@ -681,27 +752,25 @@ static int fit_front(b7_ctx *c, const b7_hyp *hyp, const double *ls_dev) {
   return launch_kxx(c, hyp->noise);
 }
 
-int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset,
-                     double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out) {
-  if (!c) return B7_ERR_INVALID;
+}  // extern "C"
+
+int eval_validate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec) {
   if (S < 1 || !hyps || !spec) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: S >= 1, hyps and spec required");
   if (spec->kind != B7_SCORE_EI && spec->kind != B7_SCORE_CB)
     return b7_fail(c, B7_ERR_INVALID, "eval_nominate: unknown score kind %d", spec->kind);
   if (spec->kind == B7_SCORE_EI && !spec->fmin) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: EI needs fmin");
-  if (global_row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: negative row offset");
   if (!c->have_data) return b7_fail(c, B7_ERR_STATE, "eval_nominate: call b7_gp_set_data first");
   if (c->M > 0 && c->d != c->dfit)
     return b7_fail(c, B7_ERR_INVALID, "eval_nominate: grid dims %d != data dims %d", c->d, c->dfit);
+  for (int s = 0; s < S; ++s) B7_TRY(check_hyp(c, &hyps[s], c->dfit));
+  return B7_OK;
+}
+
+// bots/bayesopt.lua:69-78 as stream work: zero the accumulator, then fit + posterior + score:add per hyper sample, each
+// fit's pivot report copied to its pinned slot in stream order.  Returns without waiting for any of it.
+int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec) {
   const int d = c->dfit;
-  for (int s = 0; s < S; ++s) B7_TRY(check_hyp(c, &hyps[s], d));
   B7_HIP(c, hipSetDevice(c->device));
-  if (jitter_out) std::fill(jitter_out, jitter_out + S, 0.0);
-  if (info_out) std::fill(info_out, info_out + S, 0);
-  const bool exchange = c->comm && c->comm_world > 1;
-  if (c->M == 0) {  // an empty shard: nothing to score, but the exchange is collective
-    if (!exchange) return b7_fail(c, B7_ERR_STATE, "eval_nominate: no candidate grid on this context");
-    return b7_score_finish_global(c, (double)S, global_row_offset, best_val, best_idx1);
-  }
   B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M * c->ycols));
   B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
   B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
@@ -826,29 +895,88 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
       c->Mpred = c->M;
       B7_TRY(score_add(c, spec, fd));
     }
+    // this fit's lengthscales sit in the batch staging block, not where b7_gp_append / b7_gp_fantasize look for the
+    // current fit's: the slot is declared empty, as the header says
+    c->fitted = false;
   }
-  // without a communicator the arg-max is enqueued before the host has seen any report; with one, the collective
-  // must come after the check (a rank that redoes its nomination would otherwise issue one collective too many)
-  if (!exchange) B7_TRY(b7_score_finish_global(c, (double)S, global_row_offset, best_val, best_idx1));
-  else B7_HIP(c, hipStreamSynchronize(c->stream));
-  bool clean = true;
-  for (int s = 0; s < S; ++s) clean = clean && reports[4 * s] == 0 && reports[4 * s + 1] == 0;
-  if (!clean) {
-    bool aborted = false;
-    for (int s = 0; s < S; ++s) aborted = aborted || reports[4 * s + 1] != 0;
-    if (aborted) persist_gave_up(c);
-    B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));
-    for (int s = 0; s < S; ++s) {
-      B7_TRY(fit_hyp_core(c, &hyps[s], nullptr, jitter_out ? jitter_out + s : nullptr, info_out ? info_out + s : nullptr,
-                          true));
-      c->predicted = true;
-      c->Mpred = c->M;
-      if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
-      B7_TRY(score_add(c, spec, fd));
-    }
-  }
-  if (!clean || exchange) B7_TRY(b7_score_finish_global(c, (double)S, global_row_offset, best_val, best_idx1));
   return B7_OK;
+}
+
+// after the stream has drained: did every fit of the last eval_enqueue factor at the first attempt, without a hand-off
+// time-out?
+bool eval_reports_clean(b7_ctx *c, int S) {
+  const int *reports = static_cast<const int *>(c->pin_eval);
+  bool clean = true, aborted = false;
+  for (int s = 0; s < S; ++s) {
+    clean = clean && reports[4 * s] == 0 && reports[4 * s + 1] == 0;
+    aborted = aborted || reports[4 * s + 1] != 0;
+  }
+  if (aborted) persist_gave_up(c);
+  return clean;
+}
+
+// the same nomination through the per-sample path, jitter schedule (utils/math.lua:159-218) included; synchronous
+int eval_redo(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec, double *jitter_out, int *info_out) {
+  B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));
+  double *fd = nullptr;
+  for (int s = 0; s < S; ++s) {
+    B7_TRY(fit_hyp_core(c, &hyps[s], nullptr, jitter_out ? jitter_out + s : nullptr, info_out ? info_out + s : nullptr, true));
+    c->predicted = true;
+    c->Mpred = c->M;
+    if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
+    B7_TRY(score_add(c, spec, fd));
+  }
+  return B7_OK;
+}
+
+extern "C" {
+
+int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset,
+                     double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (c->group) return b7_fail(c, B7_ERR_STATE, "eval_nominate: this context belongs to a group (b7_group_eval_nominate)");
+  const bool exchange = c->comm && c->comm_world > 1;
+  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  if (jitter_out && S > 0) std::fill(jitter_out, jitter_out + S, 0.0);
+  if (info_out && S > 0) std::fill(info_out, info_out + S, 0);
+  int rc = eval_validate(c, S, hyps, spec);
+  if (rc == B7_OK && global_row_offset < 0) rc = b7_fail(c, B7_ERR_INVALID, "eval_nominate: negative row offset");
+  if (rc == B7_OK && c->M == 0 && !exchange) rc = b7_fail(c, B7_ERR_STATE, "eval_nominate: no candidate grid on this context");
+  if (!exchange) {
+    // the arg-max and the copy of its record are enqueued before the host has seen any report: one synchronisation
+    B7_TRY(rc);
+    B7_TRY(eval_enqueue(c, S, hyps, spec));
+    B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true));
+    B7_TRY(exch_fetch(c, 0, world));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (!eval_reports_clean(c, S)) {
+      B7_TRY(eval_redo(c, S, hyps, spec, jitter_out, info_out));
+      B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true));
+      B7_TRY(exch_fetch(c, 0, world));
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
+  }
+  // with a communicator the collective comes after the report check (a rank that redoes its nomination must not
+  // issue one collective too many), and a rank that fails locally still reaches it, with a failure record
+  if (rc == B7_OK && c->M > 0) {
+    rc = eval_enqueue(c, S, hyps, spec);
+    if (rc == B7_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "eval_nominate: stream failed");
+    if (rc == B7_OK && !eval_reports_clean(c, S)) rc = eval_redo(c, S, hyps, spec, jitter_out, info_out);
+  }
+  if (rc == B7_OK) rc = exch_local(c, (double)S, global_row_offset, rank, world, true);
+  const std::string own = c->err;
+  if (rc != B7_OK) B7_TRY(exch_fail_record(c, rank, world, rc));
+  B7_TRY(exch_allreduce(c));
+  B7_TRY(exch_fetch(c, 0, world));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (rc != B7_OK) {
+    exch_forget(c);
+    c->err = own;
+    return rc;
+  }
+  return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
 }
 
 int b7_gp_fit(b7_ctx *c, const double *X, const double *Y, int N, int d, int ycols, const b7_hyp *hyp,

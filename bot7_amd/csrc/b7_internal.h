@@ -16,6 +16,18 @@ constexpr int B7_PERSIST_NMAX = 4096;  // largest padded N of the persistent Cho
 constexpr int B7_MROWS = 256; // chunk rows are multiples of this (largest candidates-per-block of any post variant)
 constexpr int B7_MAX_D = 96;  // LDS budget of the covariance kernel: (64 + 2*32) rows x (dpad+1) doubles at dpad = 96
 
+// The exchange table of a candidate-sharded nomination (comm.hip): one fixed-width record of 64-bit words per rank, so
+// that ONE all-reduce carries the arg-max pair, the winner's grid row (what bots/abstract.lua:118-121 steals into
+// `pending`), the shard's row count and a failure flag.  The width does not depend on the grid's dims: every rank issues
+// the same collective whatever it holds (an empty shard has no grid to take dims from).
+constexpr int B7_TAB_VAL = 0;     // bits of the local maximum
+constexpr int B7_TAB_IDX = 1;     // its 1-based GLOBAL index; 0 = this shard is empty
+constexpr int B7_TAB_STATUS = 2;  // 0 = fine; otherwise -(B7_ERR_*) of the rank that could not score its shard
+constexpr int B7_TAB_ROWS = 3;    // candidate rows this shard holds
+constexpr int B7_TAB_ROW0 = 4;    // d doubles: the grid row of the local maximum
+constexpr int B7_TAB_W = B7_TAB_ROW0 + B7_MAX_D;
+constexpr int B7_MAX_WORLD = 64;
+
 // Padded input dimension: the covariance kernel is instantiated per class so its MFMA chain unrolls.
 static inline int b7_dpad_class(int d) {
   return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : 96;
@@ -131,7 +143,18 @@ struct b7_ctx {
   // ---- the arg-max exchange (comm.hip): RCCL communicator of this rank, one per context = per GPU = per process
   void *comm = nullptr;  // ncclComm_t
   int comm_rank = 0, comm_world = 1;
-  DevBuf slots;  // [world, 2] x u64 exchange table (also the staging of b7_comm_allreduce_f64)
+  DevBuf slots;  // [world, B7_TAB_W] x u64 exchange table (also the staging of b7_comm_allreduce_f64)
+  uint64_t *tab_host = nullptr;  // pinned host copy of the table, B7_MAX_WORLD records
+  struct b7_group *group = nullptr;  // set while the context is a member of a single-process group (group.hip)
+  bool group_busy = false;           // ... and this while the group itself is calling the member's grid mutators
+  // the last exchange as every rank saw it: the winner (index, owning rank, grid row) and the row count of every shard.
+  // b7_nominate_commit takes the row from here, so that a model-based trial needs no second collective.
+  bool win_valid = false;
+  int64_t win_idx1 = 0;
+  int win_rank = -1, win_d = 0;
+  double win_row[B7_MAX_D];
+  int64_t shard_rows[B7_MAX_WORLD];
+  int shard_world = 0;
 
   // ---- measurement
   hipEvent_t tev[B7_MAX_TIMERS][2];
@@ -182,6 +205,8 @@ int launch_random_grid(b7_ctx *c, double *out, int64_t size, int dims, uint64_t 
                        const double *mins, const double *maxes);
 int launch_remove_row(b7_ctx *c, const double *src, double *dst, int64_t M, int d, int64_t idx0);
 int launch_remove_rows(b7_ctx *c, const double *src, double *dst, int64_t M, int d, const int64_t *cuts_dev, int ncut);
+int launch_colrange(b7_ctx *c, const double *grid, int64_t M, int d, double *out_dev);
+int launch_col_affine(b7_ctx *c, double *grid, int64_t M, int d, const double *v_dev, bool mul);
 int launch_gather_rows(b7_ctx *c, const double *src, double *out, const int64_t *idx0_dev, int64_t n, int d);
 
 // covar.hip
@@ -265,4 +290,27 @@ int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, i
 int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *best_val, int64_t *best_idx1);
 int launch_fill(b7_ctx *c, double *p, int64_t n, double v);
 int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64_t *tab_dev, int rank, int world,
-                       int64_t offset);
+                       int64_t offset, const double *grid, int d, bool all_slots);
+
+int launch_keep_record(b7_ctx *c, uint64_t *tab_dev, int rank, int world);
+int launch_row_slot(b7_ctx *c, uint64_t *tab_dev, int rank, int world, int64_t idx1_global, int64_t local0, const double *grid,
+                    int d);
+
+// comm.hip: the pieces of a sharded nomination that b7_eval_nominate, b7_score_finish_global and the single-process
+// group (group.hip) are assembled from
+int exch_table_ensure(b7_ctx *c, int world);
+int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots);  // enqueue: score:div, local arg-max, this rank's record
+int exch_fail_record(b7_ctx *c, int rank, int world, int code);  // enqueue: this rank's record says "could not score"
+int exch_allreduce(b7_ctx *c);                                   // enqueue: the collective (no-op without a communicator)
+int exch_rewrite_record(b7_ctx *c, int rank, int world);         // enqueue: zero every record but this rank's (before a repeated all-reduce)
+int exch_fetch(b7_ctx *c, int first_rank, int nranks);           // enqueue: records [first, first + n) -> pinned host copy
+bool exch_pick(const uint64_t *tab, int world, int stride, double *val, int64_t *idx1, int *rank);
+int exch_conclude(b7_ctx *c, const uint64_t *tab, int world, double *best_val, int64_t *best_idx1);  // statuses, winner, cache
+void exch_forget(b7_ctx *c);
+
+// api.hip: bayesopt:eval as stream work without a host wait, its report check and the per-sample redo
+int eval_validate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec);
+int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec);
+bool eval_reports_clean(b7_ctx *c, int S);
+int eval_redo(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec, double *jitter_out, int *info_out);
+int grid_drop_row(b7_ctx *c, int64_t local_idx1, double *row_out_sync);  // stable deletion, enqueued; row_out != NULL synchronises

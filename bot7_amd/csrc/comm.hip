@@ -15,80 +15,141 @@
 #include <string.h>
 
 #include "b7_internal.h"
-
-namespace {
-
-struct Rccl {
-  void *handle = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  std::string err;
-};
+#include "comm_rccl.h"
 
 Rccl &rccl() {
   static Rccl r;
   if (r.handle || !r.err.empty()) return r;
+  // B7_RCCL_LIB: another RCCL build, or (tests) a name that does not exist, to see the failure path without a host
+  // that lacks the library
+  const char *forced = getenv("B7_RCCL_LIB");
   const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-  for (const char *n : names) {
-    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (r.handle) break;
-  }
+  if (forced) r.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+  else
+    for (const char *n : names) {
+      r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
   if (!r.handle) {
-    r.err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+    const char *e = dlerror();  // one call: dlerror() clears the message it returns
+    r.err = std::string("dlopen(") + (forced ? forced : "librccl.so.1") + "): " + (e ? e : "not found");
     return r;
   }
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+  r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.handle, "ncclCommInitAll"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
+  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.handle, "ncclGroupStart"));
+  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.handle, "ncclGroupEnd"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
-    r.err = "librccl is missing one of ncclGetUniqueId/CommInitRank/CommDestroy/AllReduce/GetErrorString";
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd ||
+      !r.GetErrorString) {
+    r.err = "librccl is missing one of ncclGetUniqueId/CommInitRank/CommInitAll/CommDestroy/AllReduce/GroupStart/GroupEnd/GetErrorString";
     r.handle = nullptr;
   }
   return r;
 }
 
-#define B7_NCCL(c, r, expr)                                                                       \
-  do {                                                                                            \
-    ncclResult_t e__ = (expr);                                                                    \
-    if (e__ != ncclSuccess) return b7_fail((c), B7_ERR_COMM, "%s: %s", #expr, (r).GetErrorString(e__)); \
-  } while (0)
+// ---- the exchange, in pieces (b7_eval_nominate, b7_score_finish_global and group.hip assemble them) --------------------
 
-// Pinned block layout (b7_internal.h): [6144, 8192) is the host copy of the exchange table (<= 64 ranks).
-constexpr int SLOT_OFF = 6144;
-constexpr int MAX_WORLD = (8192 - SLOT_OFF) / 16;
+int exch_table_ensure(b7_ctx *c, int world) {
+  if (world < 1 || world > B7_MAX_WORLD) return b7_fail(c, B7_ERR_UNSUPPORTED, "exchange: world %d not in [1, %d]", world, B7_MAX_WORLD);
+  B7_TRY(b7_ensure(c, c->slots, sizeof(uint64_t) * B7_TAB_W * (size_t)world + sizeof(double) * 128 + 64));
+  if (!c->tab_host) B7_HIP(c, hipHostMalloc((void **)&c->tab_host, sizeof(uint64_t) * B7_TAB_W * B7_MAX_WORLD, hipHostMallocDefault));
+  return B7_OK;
+}
 
-// TH max over the gathered pairs; idx <= 0 marks an empty shard.
-bool pick_winner(const uint64_t *tab, int world, double *val, int64_t *idx1) {
+void exch_forget(b7_ctx *c) { c->win_valid = false; }
+
+// score:div + local score:max(1) on the device; this rank's record lands in the table with the index already global
+// and the grid row it names beside it (an empty shard contributes a zero record)
+int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots) {
+  B7_TRY(exch_table_ensure(c, world));
+  return launch_finish_slot(c, c->M > 0 ? (double *)c->acc.p : nullptr, c->M, divisor, (uint64_t *)c->slots.p, rank, world,
+                            offset, c->M > 0 ? (const double *)c->grid[c->grid_cur].p : nullptr, c->d, all_slots);
+}
+
+// A rank that could not score its shard still takes part in the collective: its record carries the error code, and
+// every rank returns an error together instead of the others waiting in ncclAllReduce for ever.
+int exch_fail_record(b7_ctx *c, int rank, int world, int code) {
+  B7_TRY(exch_table_ensure(c, world));
+  uint64_t *stage = c->tab_host + (size_t)(B7_MAX_WORLD - 1) * B7_TAB_W;  // last record of the pinned block: staging
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  memset(stage, 0, sizeof(uint64_t) * B7_TAB_W);
+  stage[B7_TAB_STATUS] = (uint64_t)(int64_t)(code < 0 ? -code : 1);
+  B7_HIP(c, hipMemsetAsync(c->slots.p, 0, sizeof(uint64_t) * B7_TAB_W * (size_t)world, c->stream));
+  B7_HIP(c, hipMemcpyAsync((uint64_t *)c->slots.p + (size_t)rank * B7_TAB_W, stage, sizeof(uint64_t) * B7_TAB_W,
+                           hipMemcpyHostToDevice, c->stream));
+  return B7_OK;
+}
+
+int exch_allreduce(b7_ctx *c) {
+  if (!c->comm) return B7_OK;
+  Rccl &r = rccl();
+  PhaseScope ps(c, "exchange");
+  B7_NCCL(c, r, r.AllReduce(c->slots.p, c->slots.p, (size_t)B7_TAB_W * c->comm_world, ncclUint64, ncclSum,
+                            static_cast<ncclComm_t>(c->comm), c->stream));
+  return B7_OK;
+}
+
+int exch_rewrite_record(b7_ctx *c, int rank, int world) { return launch_keep_record(c, (uint64_t *)c->slots.p, rank, world); }
+
+int exch_fetch(b7_ctx *c, int first, int n) {
+  B7_HIP(c, hipMemcpyAsync(c->tab_host + (size_t)first * B7_TAB_W, (const uint64_t *)c->slots.p + (size_t)first * B7_TAB_W,
+                           sizeof(uint64_t) * B7_TAB_W * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  return B7_OK;
+}
+
+// TH max over the gathered records; idx <= 0 marks an empty shard.
+bool exch_pick(const uint64_t *tab, int world, int stride, double *val, int64_t *idx1, int *rank_out) {
   bool have = false;
   double bv = 0.0;
   int64_t bi = 0;
+  int br = -1;
   for (int r = 0; r < world; ++r) {
     double v;
-    memcpy(&v, &tab[2 * r], sizeof(double));
-    const int64_t i = (int64_t)tab[2 * r + 1];
+    memcpy(&v, &tab[(size_t)stride * r], sizeof(double));
+    const int64_t i = (int64_t)tab[(size_t)stride * r + 1];
     if (i <= 0) continue;
     if (!have) {
-      have = true, bv = v, bi = i;
+      have = true, bv = v, bi = i, br = r;
       continue;
     }
     const bool vn = v != v, bn = bv != bv;
     if (vn || bn) {
-      if (vn && (!bn || i < bi)) bv = v, bi = i;
+      if (vn && (!bn || i < bi)) bv = v, bi = i, br = r;
     } else if (v > bv || (v == bv && i < bi)) {
-      bv = v, bi = i;
+      bv = v, bi = i, br = r;
     }
   }
   *val = bv;
   *idx1 = bi;
+  if (rank_out) *rank_out = br;
   return have;
 }
 
-}  // namespace
+int exch_conclude(b7_ctx *c, const uint64_t *tab, int world, double *best_val, int64_t *best_idx1) {
+  exch_forget(c);
+  for (int r = 0; r < world; ++r)
+    if (tab[(size_t)r * B7_TAB_W + B7_TAB_STATUS] != 0)
+      return b7_fail(c, B7_ERR_COMM, "nomination: rank %d could not score its shard (error %lld); no rank nominates", r,
+                     -(long long)tab[(size_t)r * B7_TAB_W + B7_TAB_STATUS]);
+  double v = 0.0;
+  int64_t i = 0;
+  int wr = -1;
+  if (!exch_pick(tab, world, B7_TAB_W, &v, &i, &wr)) return b7_fail(c, B7_ERR_STATE, "score_finish_global: every shard is empty");
+  c->win_valid = true;
+  c->win_idx1 = i;
+  c->win_rank = wr;
+  c->win_d = c->d;
+  memcpy(c->win_row, &tab[(size_t)wr * B7_TAB_W + B7_TAB_ROW0], sizeof(double) * B7_MAX_D);
+  c->shard_world = world;
+  for (int r = 0; r < world; ++r) c->shard_rows[r] = (int64_t)tab[(size_t)r * B7_TAB_W + B7_TAB_ROWS];
+  if (best_val) *best_val = v;
+  if (best_idx1) *best_idx1 = i;
+  return B7_OK;
+}
 
 extern "C" {
 
@@ -96,9 +157,18 @@ int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int6
   if (!table || world < 1) return B7_ERR_INVALID;
   double v = 0.0;
   int64_t i = 0;
-  if (!pick_winner(table, world, &v, &i)) return B7_ERR_STATE;  // every shard empty
+  if (!exch_pick(table, world, 2, &v, &i, nullptr)) return B7_ERR_STATE;  // every shard empty
   if (best_val) *best_val = v;
   if (best_idx1) *best_idx1 = i;
+  return B7_OK;
+}
+
+int b7_shard_commit_rule(int64_t idx1_global, int64_t offset, int64_t M_local, int64_t *local_idx1, int64_t *new_offset) {
+  if (idx1_global < 1 || offset < 0 || M_local < 0) return B7_ERR_INVALID;
+  const bool mine = idx1_global > offset && idx1_global <= offset + M_local;
+  if (local_idx1) *local_idx1 = mine ? idx1_global - offset : 0;
+  // the deleted row lies in a shard before this one: every row of this shard moves up by one in the union
+  if (new_offset) *new_offset = (idx1_global <= offset) ? offset - 1 : offset;
   return B7_OK;
 }
 
@@ -117,8 +187,9 @@ int b7_comm_init(b7_ctx *c, int rank, int world, const void *id_bytes) {
   if (!c) return B7_ERR_INVALID;
   if (!id_bytes || world < 1 || rank < 0 || rank >= world)
     return b7_fail(c, B7_ERR_INVALID, "comm_init: rank %d of %d", rank, world);
-  if (world > MAX_WORLD) return b7_fail(c, B7_ERR_UNSUPPORTED, "comm_init: world %d > %d", world, MAX_WORLD);
+  if (world > B7_MAX_WORLD) return b7_fail(c, B7_ERR_UNSUPPORTED, "comm_init: world %d > %d", world, B7_MAX_WORLD);
   if (c->comm) return b7_fail(c, B7_ERR_STATE, "comm_init: this context already has a communicator");
+  if (c->group) return b7_fail(c, B7_ERR_STATE, "comm_init: this context belongs to a single-process group");
   Rccl &r = rccl();
   if (!r.handle) return b7_fail(c, B7_ERR_COMM, "%s", r.err.c_str());
   B7_HIP(c, hipSetDevice(c->device));
@@ -129,8 +200,8 @@ int b7_comm_init(b7_ctx *c, int rank, int world, const void *id_bytes) {
   c->comm = comm;
   c->comm_rank = rank;
   c->comm_world = world;
-  B7_TRY(b7_ensure(c, c->slots, sizeof(uint64_t) * 2 * (size_t)world + 64));
-  return B7_OK;
+  exch_forget(c);
+  return exch_table_ensure(c, world);
 }
 
 int b7_comm_info(b7_ctx *c, int *rank, int *world) {
@@ -150,6 +221,7 @@ int b7_comm_destroy(b7_ctx *c) {
   c->comm = nullptr;
   c->comm_world = 1;
   c->comm_rank = 0;
+  exch_forget(c);
   if (r.handle) B7_NCCL(c, r, r.CommDestroy(comm));
   return B7_OK;
 }
@@ -165,12 +237,12 @@ int b7_comm_allreduce_f64(b7_ctx *c, double *inout, int n, int op) {
     return B7_OK;
   }
   Rccl &r = rccl();
-  B7_TRY(b7_ensure(c, c->slots, sizeof(double) * 128 + 64));
-  B7_HIP(c, hipMemcpyAsync(c->slots.p, inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(exch_table_ensure(c, c->comm_world));
+  double *stage = (double *)((uint64_t *)c->slots.p + (size_t)B7_TAB_W * c->comm_world);  // behind the table
+  B7_HIP(c, hipMemcpyAsync(stage, inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   const ncclRedOp_t rop = op == B7_COMM_SUM ? ncclSum : op == B7_COMM_MAX ? ncclMax : ncclMin;
-  B7_NCCL(c, r, r.AllReduce(c->slots.p, c->slots.p, (size_t)n, ncclDouble, rop, static_cast<ncclComm_t>(c->comm),
-                            c->stream));
-  B7_HIP(c, hipMemcpyAsync(inout, c->slots.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  B7_NCCL(c, r, r.AllReduce(stage, stage, (size_t)n, ncclDouble, rop, static_cast<ncclComm_t>(c->comm), c->stream));
+  B7_HIP(c, hipMemcpyAsync(inout, stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
 }
@@ -178,30 +250,98 @@ int b7_comm_allreduce_f64(b7_ctx *c, double *inout, int n, int op) {
 int b7_score_finish_global(b7_ctx *c, double divisor, int64_t global_row_offset, double *best_val,
                            int64_t *best_idx1) {
   if (!c) return B7_ERR_INVALID;
-  if (global_row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "score_finish_global: negative row offset");
-  if (c->M > 0 && !c->acc_valid) return b7_fail(c, B7_ERR_STATE, "score_finish_global: call b7_score_reset first");
-  B7_HIP(c, hipSetDevice(c->device));
+  if (c->group) return b7_fail(c, B7_ERR_STATE, "score_finish_global: this context belongs to a group (b7_group_eval_nominate)");
   const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
-  B7_TRY(b7_ensure(c, c->slots, sizeof(uint64_t) * 2 * (size_t)world + 64));
-  uint64_t *tab_dev = static_cast<uint64_t *>(c->slots.p);
-  // score:div + local score:max(1) on the device; the pair lands in this rank's slot of the zeroed table with the
-  // index already global (an empty shard contributes (0, 0))
-  B7_TRY(launch_finish_slot(c, c->M > 0 ? (double *)c->acc.p : nullptr, c->M, divisor, tab_dev, rank, world,
-                            global_row_offset));
-  if (c->comm) {
-    Rccl &r = rccl();
-    PhaseScope ps(c, "exchange");
-    B7_NCCL(c, r, r.AllReduce(tab_dev, tab_dev, 2 * (size_t)world, ncclUint64, ncclSum,
-                              static_cast<ncclComm_t>(c->comm), c->stream));
+  int rc = B7_OK;
+  if (global_row_offset < 0) rc = b7_fail(c, B7_ERR_INVALID, "score_finish_global: negative row offset");
+  else if (c->M > 0 && !c->acc_valid) rc = b7_fail(c, B7_ERR_STATE, "score_finish_global: call b7_score_reset first");
+  if (rc == B7_OK) rc = hipSetDevice(c->device) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "hipSetDevice failed");
+  if (rc == B7_OK) rc = exch_local(c, divisor, global_row_offset, rank, world, true);
+  if (rc != B7_OK) {
+    if (world == 1) return rc;
+    const std::string own = c->err;
+    B7_TRY(exch_fail_record(c, rank, world, rc));  // reach the collective all the same
+    B7_TRY(exch_allreduce(c));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    exch_forget(c);
+    c->err = own;
+    return rc;
   }
-  uint64_t *tab = reinterpret_cast<uint64_t *>(static_cast<char *>(c->pinned) + SLOT_OFF);
-  B7_HIP(c, hipMemcpyAsync(tab, tab_dev, sizeof(uint64_t) * 2 * world, hipMemcpyDeviceToHost, c->stream));
+  B7_TRY(exch_allreduce(c));
+  B7_TRY(exch_fetch(c, 0, world));
   B7_HIP(c, hipStreamSynchronize(c->stream));
-  double v = 0.0;
-  int64_t i = 0;
-  if (!pick_winner(tab, world, &v, &i)) return b7_fail(c, B7_ERR_STATE, "score_finish_global: every shard is empty");
-  if (best_val) *best_val = v;
-  if (best_idx1) *best_idx1 = i;
+  return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
+}
+
+int b7_exchange_info(b7_ctx *c, int *world_out, int64_t *rows_per_rank, int64_t *winner_idx1, int *winner_rank,
+                     double *winner_row) {
+  if (!c) return B7_ERR_INVALID;
+  if (!c->win_valid) return b7_fail(c, B7_ERR_STATE, "exchange_info: no nomination since the grid last changed");
+  if (world_out) *world_out = c->shard_world;
+  if (rows_per_rank) memcpy(rows_per_rank, c->shard_rows, sizeof(int64_t) * c->shard_world);
+  if (winner_idx1) *winner_idx1 = c->win_idx1;
+  if (winner_rank) *winner_rank = c->win_rank;
+  if (winner_row) memcpy(winner_row, c->win_row, sizeof(double) * c->win_d);
+  return B7_OK;
+}
+
+// bots/abstract.lua:118 on a sharded candidate set: `steal(pending, candidates, idx)` = the winner's row for every rank
+// + utils.tensor.remove's stable deletion on the union of the shards (utils/tensor.lua:158-170): the owner compacts its
+// shard on the device, every shard behind it moves up by one global index, shards before it are untouched.
+int b7_nominate_commit(b7_ctx *c, int64_t idx1_global, int64_t *global_row_offset, double *row_out) {
+  if (!c) return B7_ERR_INVALID;
+  if (!global_row_offset) return b7_fail(c, B7_ERR_INVALID, "nominate_commit: global_row_offset is NULL");
+  if (c->group) return b7_fail(c, B7_ERR_STATE, "nominate_commit: this context belongs to a group (b7_group_nominate_commit)");
+  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  int64_t local = 0, new_off = *global_row_offset;
+  if (b7_shard_commit_rule(idx1_global, *global_row_offset, c->M, &local, &new_off) != B7_OK)
+    return b7_fail(c, B7_ERR_INVALID, "nominate_commit: index %lld, offset %lld", (long long)idx1_global, (long long)*global_row_offset);
+  B7_HIP(c, hipSetDevice(c->device));
+  const int d = c->d;
+  // the row: every rank already holds it when idx is the winner of the last exchange (the model-based trials);
+  // otherwise (the random initial trials, bots/bayesopt.lua:90-91) the owner broadcasts it with one more all-reduce.
+  // Every rank takes the same branch: they all saw the same exchange and are all told the same idx.
+  const bool cached = c->win_valid && c->win_idx1 == idx1_global;
+  double row[B7_MAX_D];
+  if (cached) {
+    if (world > 1 && (c->win_rank == rank) != (local > 0))
+      return b7_fail(c, B7_ERR_INVALID, "nominate_commit: offset %lld does not agree with the exchange (winner on rank %d)",
+                     (long long)*global_row_offset, c->win_rank);
+    if (world == 1 && local == 0) return b7_fail(c, B7_ERR_INVALID, "nominate_commit: index %lld outside the grid", (long long)idx1_global);
+    memcpy(row, c->win_row, sizeof(double) * B7_MAX_D);
+  } else if (world == 1) {
+    if (local == 0)
+      return b7_fail(c, B7_ERR_INVALID, "nominate_commit: index %lld outside (%lld, %lld]", (long long)idx1_global,
+                     (long long)*global_row_offset, (long long)(*global_row_offset + c->M));
+    B7_HIP(c, hipMemcpyAsync(row, (const double *)c->grid[c->grid_cur].p + (local - 1) * d, sizeof(double) * d,
+                             hipMemcpyDeviceToHost, c->stream));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+  } else {
+    int rc = exch_table_ensure(c, world);
+    if (rc == B7_OK)
+      rc = launch_row_slot(c, (uint64_t *)c->slots.p, rank, world, idx1_global, local > 0 ? local - 1 : -1,
+                           c->M > 0 ? (const double *)c->grid[c->grid_cur].p : nullptr, d);
+    if (rc != B7_OK) B7_TRY(exch_fail_record(c, rank, world, rc));
+    B7_TRY(exch_allreduce(c));
+    B7_TRY(exch_fetch(c, 0, world));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    B7_TRY(rc);
+    int owner = -1;
+    for (int r = 0; r < world; ++r) {
+      const uint64_t *rec = c->tab_host + (size_t)r * B7_TAB_W;
+      if (rec[B7_TAB_STATUS] != 0) return b7_fail(c, B7_ERR_COMM, "nominate_commit: rank %d failed (error %lld)", r, -(long long)rec[B7_TAB_STATUS]);
+      if ((int64_t)rec[B7_TAB_IDX] == idx1_global) {
+        if (owner >= 0) return b7_fail(c, B7_ERR_INVALID, "nominate_commit: ranks %d and %d both claim index %lld (overlapping offsets)", owner, r, (long long)idx1_global);
+        owner = r;
+      }
+    }
+    if (owner < 0) return b7_fail(c, B7_ERR_INVALID, "nominate_commit: index %lld lies in no rank's shard", (long long)idx1_global);
+    memcpy(row, c->tab_host + (size_t)owner * B7_TAB_W + B7_TAB_ROW0, sizeof(double) * B7_MAX_D);
+  }
+  if (local > 0) B7_TRY(grid_drop_row(c, local, nullptr));  // enqueued: the next nomination runs behind it on the same stream
+  *global_row_offset = new_off;
+  if (row_out) memcpy(row_out, row, sizeof(double) * d);
+  exch_forget(c);
   return B7_OK;
 }
 

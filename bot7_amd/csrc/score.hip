@@ -176,20 +176,42 @@ __global__ void __launch_bounds__(256) argmax_final_kernel(const Best *__restric
   if (threadIdx.x == 0) out[0] = b;
 }
 
-// The global-exchange form of argmax_final_kernel: this rank's (value bits, 1-based GLOBAL index) goes into slot
-// `rank` of the [world, 2] table of 64-bit words, every other slot is zeroed (comm.hip sums the tables of all ranks).
+// The global-exchange form of argmax_final_kernel: this rank's record of the exchange table (b7_internal.h: value bits,
+// 1-based GLOBAL index, status 0, shard rows, the winner's grid row).  With all_slots the records of every other rank are
+// zeroed as well (comm.hip sums the tables of all ranks); a single-process group merges records on the host and needs
+// only this one.
 __global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict__ part, int n, unsigned long long *__restrict__ tab,
-                                                          int rank, int world, long long offset) {
+                                                          int rank, int world, long long offset, long long rows,
+                                                          const double *__restrict__ grid, int d, int all_slots,
+                                                          long long forced_local) {
   __shared__ Best sh[4];
   Best b{0.0, -1};
-  for (int j = threadIdx.x; j < n; j += blockDim.x)
-    if (better(part[j], b)) b = part[j];
-  b = block_best(b, sh);
-  for (int r = threadIdx.x; r < world; r += blockDim.x) {
-    const bool mine = r == rank && b.i >= 0;
-    tab[2 * r] = mine ? (unsigned long long)__double_as_longlong(b.v) : 0ull;
-    tab[2 * r + 1] = mine ? (unsigned long long)(offset + b.i + 1) : 0ull;
+  if (n > 0) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+      if (better(part[j], b)) b = part[j];
+    b = block_best(b, sh);
+  } else if (forced_local >= 0) {  // no scores: the record names a given row (b7_nominate_commit's broadcast)
+    b = Best{0.0, forced_local};
   }
+  if (all_slots)
+    for (int e = threadIdx.x; e < world * B7_TAB_W; e += blockDim.x)
+      if (e / B7_TAB_W != rank) tab[e] = 0ull;
+  unsigned long long *rec = tab + (size_t)rank * B7_TAB_W;
+  const bool have = b.i >= 0;
+  for (int e = threadIdx.x; e < B7_TAB_W; e += blockDim.x) {
+    unsigned long long w = 0ull;
+    if (e == B7_TAB_VAL) w = have ? (unsigned long long)__double_as_longlong(b.v) : 0ull;
+    else if (e == B7_TAB_IDX) w = have ? (unsigned long long)(offset + b.i + 1) : 0ull;
+    else if (e == B7_TAB_ROWS) w = (unsigned long long)rows;
+    else if (e >= B7_TAB_ROW0 && e - B7_TAB_ROW0 < d && have && grid)
+      w = (unsigned long long)__double_as_longlong(grid[b.i * d + (e - B7_TAB_ROW0)]);
+    rec[e] = w;
+  }
+}
+
+__global__ void __launch_bounds__(256) keep_record_kernel(unsigned long long *__restrict__ tab, int rank, int world) {
+  for (int e = threadIdx.x; e < world * B7_TAB_W; e += blockDim.x)
+    if (e / B7_TAB_W != rank) tab[e] = 0ull;
 }
 
 int nblocks(b7_ctx *c, int64_t n) {
@@ -264,17 +286,35 @@ int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *bes
   return B7_OK;
 }
 
-// launch_finish without the host round trip: the local result stays on the device, in this rank's slot of the
-// exchange table.  M == 0 (an empty shard) writes an all-zero table.
+// launch_finish without the host round trip: the local result stays on the device, in this rank's record of the
+// exchange table, together with the grid row it names.  M == 0 (an empty shard) writes an all-zero record.
 int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64_t *tab_dev, int rank, int world,
-                       int64_t offset) {
+                       int64_t offset, const double *grid, int d, bool all_slots) {
   PhaseScope ps(c, "argmax");
   const int nb = M > 0 ? nblocks(c, M) : 0;
   B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
   Best *part = (Best *)c->part.p;
   if (nb > 0) hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, c->stream, acc, M, divisor, part);
   hipLaunchKernelGGL(argmax_slot_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb,
-                     (unsigned long long *)tab_dev, rank, world, (long long)offset);
+                     (unsigned long long *)tab_dev, rank, world, (long long)offset, (long long)M, grid, d, all_slots ? 1 : 0,
+                     -1ll);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+// The record of a row broadcast: the rank that holds global row idx1_global (local0 >= 0, 0-based within its shard) writes
+// (0.0, idx1_global, 0, rows, the row); every other rank writes zeros.
+int launch_row_slot(b7_ctx *c, uint64_t *tab_dev, int rank, int world, int64_t idx1_global, int64_t local0, const double *grid,
+                    int d) {
+  hipLaunchKernelGGL(argmax_slot_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)nullptr, 0,
+                     (unsigned long long *)tab_dev, rank, world, (long long)(idx1_global - 1 - (local0 >= 0 ? local0 : 0)),
+                     (long long)c->M, grid, d, 1, (long long)local0);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_keep_record(b7_ctx *c, uint64_t *tab_dev, int rank, int world) {
+  hipLaunchKernelGGL(keep_record_kernel, dim3(1), dim3(256), 0, c->stream, (unsigned long long *)tab_dev, rank, world);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

@@ -162,6 +162,60 @@ __global__ void __launch_bounds__(256) random_grid_kernel(double *__restrict__ o
   }
 }
 
+// grid:min(1) / grid:max(1) (grids/sobol.lua:83,85): column minima and maxima.  A launch uses a thread count that is a
+// multiple of d, so a thread stays in one column while it strides through the (row-major, coalesced) grid; a block folds
+// its threads per column through LDS and writes one partial per column, the last kernel folds the blocks.  min / max are
+// exact in any order.
+__global__ void __launch_bounds__(256) colrange_kernel(const double *__restrict__ g, int64_t total, int d, int64_t nthreads,
+                                                       double *__restrict__ part) {
+  __shared__ double smin[256], smax[256];
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  if (t < nthreads)
+    for (int64_t e = t; e < total; e += nthreads) {
+      const double x = g[e];
+      lo = x < lo ? x : lo;
+      hi = x > hi ? x : hi;
+    }
+  smin[threadIdx.x] = lo;
+  smax[threadIdx.x] = hi;
+  __syncthreads();
+  if ((int)threadIdx.x < d) {
+    // threads j of this block with (block base + j) % d == my column
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int col = (int)((base + threadIdx.x) % d);
+    for (int j = threadIdx.x + d; j < (int)blockDim.x; j += d) {
+      lo = smin[j] < lo ? smin[j] : lo;
+      hi = smax[j] > hi ? smax[j] : hi;
+    }
+    part[((size_t)blockIdx.x * d + col) * 2] = lo;
+    part[((size_t)blockIdx.x * d + col) * 2 + 1] = hi;
+  }
+}
+__global__ void __launch_bounds__(128) colrange_final_kernel(const double *__restrict__ part, int nblk, int d,
+                                                             double *__restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= d) return;
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (int b = 0; b < nblk; ++b) {
+    const double a = part[((size_t)b * d + k) * 2], z = part[((size_t)b * d + k) * 2 + 1];
+    lo = a < lo ? a : lo;
+    hi = z > hi ? z : hi;
+  }
+  out[k] = lo;
+  out[d + k] = hi;
+}
+
+// x += v[col] (grids/sobol.lua:83) or x *= v[col] (:85): one rounded operation per element
+__global__ void __launch_bounds__(256) col_affine_kernel(double *__restrict__ g, int64_t total, int d,
+                                                         const double *__restrict__ v, int mul) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int col = (int)(e % d);
+    g[e] = mul ? g[e] * v[col] : g[e] + v[col];
+  }
+}
+
 __global__ void __launch_bounds__(256) remove_row_kernel(const double *__restrict__ src, double *__restrict__ dst,
                                                          int64_t total_out, int64_t cut, int d) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -282,5 +336,26 @@ int launch_gather_rows(b7_ctx *c, const double *src, double *out, const int64_t 
                        idx0_dev, total, d);
     B7_HIP(c, hipGetLastError());
   }
+  return B7_OK;
+}
+
+// out_dev[0..d) = column minima, [d..2d) = column maxima of the M x d grid (M > 0)
+int launch_colrange(b7_ctx *c, const double *grid, int64_t M, int d, double *out_dev) {
+  const int64_t total = M * d;
+  int nblk = grid_blocks(c, total);
+  if (nblk > 256) nblk = 256;
+  const int64_t nthreads = (int64_t)nblk * 256 / d * d;  // >= d since d <= 96 < 256
+  B7_TRY(b7_ensure(c, c->part, sizeof(double) * 2 * (size_t)nblk * d));
+  hipLaunchKernelGGL(colrange_kernel, dim3(nblk), dim3(256), 0, c->stream, grid, total, d, nthreads, (double *)c->part.p);
+  hipLaunchKernelGGL(colrange_final_kernel, dim3(1), dim3(128), 0, c->stream, (const double *)c->part.p, nblk, d, out_dev);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_col_affine(b7_ctx *c, double *grid, int64_t M, int d, const double *v_dev, bool mul) {
+  const int64_t total = M * d;
+  if (total <= 0) return B7_OK;
+  hipLaunchKernelGGL(col_affine_kernel, dim3(grid_blocks(c, total)), dim3(256), 0, c->stream, grid, total, d, v_dev, mul ? 1 : 0);
+  B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

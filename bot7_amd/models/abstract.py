@@ -23,3 +23,8 @@ class abstract(object):
 
     def __str__(self):
         return self.title
+
+
+# config.sampler -> class (bots/bayesopt.lua:44).  The samplers are host code that stays in the reference's own Lua
+# (samplers/slice.lua); whoever provides them registers them here (the test harness registers its stand-in).
+sampler_registry = {}

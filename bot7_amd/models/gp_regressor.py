@@ -91,6 +91,14 @@ class gp_regressor(abstract):
         self.nEvals = getattr(self, "nEvals", 0) + 1
         return -float(self.nll(X_obs, Y_obs, self._from_theta(theta))[0])
 
+    def _samplers(self):
+        from .abstract import sampler_registry
+        name = self.config.get("sampler", "slice")
+        if name not in sampler_registry:
+            raise KeyError("no sampler %r registered in bot7_amd.models.abstract.sampler_registry (the reference's "
+                           "bot7.samplers is host code outside this package)" % name)
+        return sampler_registry
+
     def sample_hypers(self, X_obs, Y_obs, _a=None, _b=None, state=None):
         """model:sample_hypers(X, Y[, nil, nil, true]) (bots/bayesopt.lua:68,74) -> flat hyper vector.
 
@@ -104,7 +112,7 @@ class gp_regressor(abstract):
         if self.config.get("sample") and int(self.config.get("chains", 1)) > 1:
             return self._sample_hypers_chains(X, Y, state)
         if self.config.get("sample"):
-            from ..samplers import registry as Samplers
+            Samplers = self._samplers()
             if getattr(self, "_sampler", None) is None:
                 self._sampler = Samplers[self.config.get("sampler", "slice")]()
                 self._sopt = self._sampler.configure(dict(self.config.get("sampler_opt") or {},
@@ -133,7 +141,7 @@ class gp_regressor(abstract):
         what one does."""
         C = int(self.config["chains"])
         if getattr(self, "_chain_thetas", None) is None:
-            from ..samplers import registry as Samplers
+            Samplers = self._samplers()
             self._sampler = Samplers[self.config.get("sampler", "slice")]()
             self._sopt = self._sampler.configure(dict(self.config.get("sampler_opt") or {}))
             self._sopt.setdefault("width", 0.5)

@@ -7,9 +7,9 @@ import copy
 
 import numpy as np
 
-from .. import grids as Grids
-from ..grids.abstract import DeviceGrid
-from ..utils import tensor as T
+from bot7_amd import grids as Grids
+from bot7_amd.grids.abstract import DeviceGrid
+from .. import tensor as T
 
 
 class abstract(object):
@@ -71,6 +71,13 @@ class abstract(object):
     def _steal_candidate(self, idx1):
         """pending, candidates = steal(pending, candidates, idx)  (bots/abstract.lua:118)."""
         cand = self.candidates
+        if hasattr(cand, "commit"):
+            # the candidate set is sharded over GPUs (harness/dist.py: ShardedScorer per rank, GroupCandidates in one
+            # process): idx1 is 1-based in the UNION; the library hands every rank the nominee's coordinates and deletes
+            # the row where it lives (b7_nominate_commit / b7_group_nominate_commit)
+            row = np.asarray(cand.commit(idx1), dtype=np.float64)
+            self.pending = T.append(self.pending, row.reshape(1, -1))
+            return
         row = np.array(cand[idx1 - 1], dtype=np.float64)
         self.pending = T.append(self.pending, row.reshape(1, -1))
         host = T.remove(np.asarray(cand), [idx1])

@@ -9,8 +9,8 @@ synchronisation instead of one per sample (config.bot.fused, default True)."""
 import numpy as np
 
 from .abstract import abstract
-from .. import models as Models
-from .. import scores as Scores
+from bot7_amd import models as Models
+from bot7_amd import scores as Scores
 
 
 class bayesopt(abstract):
@@ -54,6 +54,15 @@ class bayesopt(abstract):
         model.sample_hypers(X_obs, Y_obs)                         # :68 (burn-in call)
         nSamples = self.config["bot"]["nSamples"]
         spec = getattr(self.score, "device_spec", None)
+        if hasattr(X_hid, "commit"):
+            # a candidate set sharded over GPUs: every shard scores its rows, ONE exchange names the winner in the union
+            # (b7_eval_nominate with a communicator / b7_group_eval_nominate); ranks run this loop in lock step
+            hyps = [model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True)) for _ in range(nSamples)]
+            X_hid.stage_data(X_obs, Y_obs)
+            sp = spec(Y_obs)
+            val, idx = X_hid.eval_nominate(hyps, sp)
+            self.last_scores = None
+            return None, val, idx
         if spec is not None and self.config["bot"].get("fused", True) and hasattr(model, "stage"):
             # (the driver never hands pending points to the score, :66,76)
             hyps = [model.parse_hypers(model.sample_hypers(X_obs, Y_obs, None, None, True)) for _ in range(nSamples)]

@@ -1,6 +1,9 @@
-"""Multi-GPU layout of the scoring path: one process per GPU, candidates sharded by contiguous row ranges, ONE tiny
-exchange per nomination -- b7_score_finish_global in libbot7hip.so (csrc/comm.hip: ncclAllReduce over xGMI).  This
-module is the host-side arithmetic around it (shard ranges, the winner rule restated for the gloo rehearsal).
+"""HARNESS.  Multi-GPU layout of the scoring path: one process per GPU, candidates sharded by contiguous row ranges, ONE tiny
+exchange per nomination -- b7_score_finish_global / b7_eval_nominate in libbot7hip.so (csrc/comm.hip: ncclAllReduce over
+xGMI) -- and the stable deletion of the nominee on the union of the shards (b7_nominate_commit).  This module is the
+host-side arithmetic around it (shard ranges, the winner rule restated for the gloo rehearsal) and the two candidate
+stores the harness bot (harness/bots) runs the reference's trial loop on: ShardedScorer (this rank's shard, one process
+per GPU) and GroupCandidates (one process, several GPUs: b7_group_*).
 
 Candidates are independent given the fitted GP (bots/bayesopt.lua:56-99 scores them elementwise and takes one
 max), so rank r of G owns rows [lo, hi) of the global grid, generates them itself (Sobol is closed-form per
@@ -73,6 +76,43 @@ class ShardedScorer(object):
         self.ctx, self.M_global, self.rank, self.world = ctx, int(M_global), int(rank), int(world)
         self.lo, self.hi = shard_range(M_global, rank, world)
 
+    # ---- what harness/bots needs of a candidate set that is not a host tensor ----------------------------------------
+    @property
+    def shape(self):
+        """(rows of the UNION, dims): bots/bayesopt.lua:91 draws the initial picks against candidates:size(1)."""
+        return (self.M_global, self.ctx.grid_shape()[1])
+
+    def stage_data(self, X_obs, Y_obs):
+        self.ctx.gp_set_data(X_obs, Y_obs)
+
+    def commit(self, idx1_global, device=None, group=None):
+        """bots/abstract.lua:118 steal(pending, candidates, idx) on the sharded set: the nominee's coordinates on every
+        rank, its stable deletion on the owner, the offset shift behind it.  Product path: ONE C-ABI call,
+        b7_nominate_commit (the row rides in the exchange record of the nomination; the random initial picks cost one
+        more all-reduce).  gloo rehearsal: the library's own bookkeeping rule (b7_shard_commit_rule, host-only) + a
+        torch.distributed sum that broadcasts the owner's row."""
+        if self.ctx.comm_info()[1] == self.world:
+            row, self.lo = self.ctx.nominate_commit(idx1_global, self.lo)
+        else:
+            import torch
+            import torch.distributed as dist
+            from bot7_amd import _lib
+            M_local = self.hi - self.lo
+            loc, new_lo = _lib.shard_commit_rule(idx1_global, self.lo, M_local)
+            d = self.ctx.grid_shape()[1]
+            row = torch.zeros(d + 1, dtype=torch.float64)
+            if loc > 0:
+                row[:d] = torch.from_numpy(np.asarray(self.ctx.grid_remove(loc), dtype=np.float64))
+                row[d] = 1.0
+            dist.all_reduce(row, op=dist.ReduceOp.SUM, group=group)
+            if row[d].item() != 1.0:
+                raise ValueError("index %d lies in %d shards" % (idx1_global, int(row[d].item())))
+            row = row[:d].numpy().copy()
+            self.lo = new_lo
+        self.M_global -= 1
+        self.hi = self.lo + self.ctx.grid_shape()[0]
+        return row
+
     def make_sobol(self, dims, skip=1, mins=None, maxes=None, download=False):
         return self.ctx.grid_sobol(self.hi - self.lo, dims, skip + self.lo, mins, maxes, download=download)
 
@@ -110,3 +150,24 @@ class ShardedScorer(object):
         else:
             v, i = 0.0, 0
         return exchange_best(v, i, self.lo, device=device, group=group)
+
+
+class GroupCandidates(object):
+    """The candidate set of a single-process group (bot7_amd.Group, b7_group_*): what harness/bots calls on it."""
+
+    def __init__(self, group):
+        self.group = group
+
+    @property
+    def shape(self):
+        M, d, _ = self.group.grid_shape()
+        return (M, d)
+
+    def stage_data(self, X_obs, Y_obs):
+        self.group.gp_set_data(X_obs, Y_obs)
+
+    def eval_nominate(self, hyps, spec, device=None, group=None):
+        return self.group.eval_nominate(hyps, **spec)
+
+    def commit(self, idx1_global, device=None, group=None):
+        return self.group.nominate_commit(idx1_global)

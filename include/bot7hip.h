@@ -57,9 +57,11 @@ int b7_set_workspace(b7_ctx *ctx, int64_t bytes);
 
 /* grids/sobol.lua:58-90 generate + :216-335 i4_sobol.  Row j (1-based) is Sobol point number
  * j + skip - 1 (Gray-code order, 30 bits), then x*(maxes-mins)+mins as two rounded ops (:79-81);
- * mins/maxes both NULL = no affine map.  The grid stays resident on the device as THE candidate set;
- * out_host (nullable, size x dims) receives a copy.  dims must be < 40 (:36).  A rank that owns rows
- * [lo, hi) of a global grid calls this with size = hi-lo and skip = global_skip + lo. */
+ * mins/maxes both NULL = no affine map; mins only: x + (mins + column minimum) (:82-83, as the reference writes it);
+ * maxes only: x * (maxes / column maximum) (:84-85) -- the column extremes are those of the WHOLE grid: a context with a
+ * communicator combines them across ranks (one all-reduce of d doubles; collective).  The grid stays resident on the
+ * device as THE candidate set; out_host (nullable, size x dims) receives a copy.  dims must be < 40 (:36).  A rank that
+ * owns rows [lo, hi) of a global grid calls this with size = hi-lo and skip = global_skip + lo. */
 int b7_grid_sobol(b7_ctx *ctx, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
                   double *out_host);
 
@@ -72,6 +74,11 @@ int b7_sobol_direction_numbers(int dims, uint32_t *out);
  * scaled by 2^-53, then the same affine map.  Any dims. */
 int b7_grid_random(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins,
                    const double *maxes, double *out_host);
+
+/* The pieces of the one-sided maps, for callers that combine shards themselves: grid:min(1) / grid:max(1) of the resident
+ * grid (both nullable, d entries), and the map itself given the extremes of the whole grid (exactly one of mins / maxes). */
+int b7_grid_colrange(b7_ctx *ctx, double *col_min, double *col_max);
+int b7_grid_apply_onesided(b7_ctx *ctx, const double *mins, const double *maxes, const double *col_ext);
 
 /* A caller-made grid (cache.candidates, bots/abstract.lua:30). */
 int b7_grid_upload(b7_ctx *ctx, const double *X_hid, int64_t M, int d);
@@ -143,7 +150,7 @@ int b7_gp_predict_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *mean_host, double 
  * per fit: jitter_out[B] / info_out[B], nullable).  The B factorisations run concurrently in ONE persistent launch (each
  * a chain of workgroups; 28 fit on the chip at N <= 256, 7 at N <= 512, larger ones go one after the other), with L z = r
  * solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched.
- * One response column, N <= 2048. */
+ * One response column, N <= 4096. */
 int b7_gp_nll_batch(b7_ctx *ctx, int B, const double *lenscale_sq, const double *amp, const double *noise,
                     const double *mean, double *nll_out, double *jitter_out, int *info_out);
 
@@ -232,8 +239,13 @@ int b7_score_finish(b7_ctx *ctx, double divisor, double *best_val, int64_t *best
  * Layout: one process per GPU, each with its own context; rank r owns candidate rows
  * [offset_r, offset_r + M_r) of the global grid (it generates them itself: b7_grid_sobol with skip + offset_r),
  * refits the GP redundantly, accumulates scores locally.  bots/bayesopt.lua:95-96's score:max(1) over ALL
- * candidates is then ONE ncclAllReduce of a [world, 2] table of 64-bit words inside b7_score_finish_global.
- * librccl is dlopen'ed at the first b7_comm_* call; a context without a communicator is a world of one. */
+ * candidates is then ONE ncclAllReduce inside b7_score_finish_global / b7_eval_nominate, over a table with one
+ * fixed-width record of 64-bit words per rank: (value bits, global 1-based index, failure flag, rows of the shard,
+ * the winner's grid row) -- so the same exchange also delivers what bots/abstract.lua:118-121 needs next, the
+ * nominee's coordinates, to every rank (b7_nominate_commit), and a rank that could not score its shard makes every
+ * rank return an error instead of leaving the others inside the collective.  800 B per rank, latency-bound.
+ * librccl is dlopen'ed at the first b7_comm_* call; a context without a communicator is a world of one.
+ * (One process driving several GPUs: the b7_group_* calls further down.) */
 #define B7_COMM_ID_BYTES 128
 /* ncclGetUniqueId: rank 0 makes the id (no context needed) and hands the 128 bytes to the other ranks by whatever
  * channel the host has (a file, an environment variable, a socket). */
@@ -249,8 +261,8 @@ int b7_comm_destroy(b7_ctx *ctx); /* also done by b7_destroy */
 #define B7_COMM_MAX 1
 #define B7_COMM_MIN 2
 int b7_comm_allreduce_f64(b7_ctx *ctx, double *inout, int n, int op);
-/* Host-only, needs no context and no GPU: the rule every rank applies to the gathered [world, 2] table of 64-bit words
- * (value bits, global 1-based index; index 0 = that rank's shard was empty) -- TH's max over the union of the shards:
+/* Host-only, needs no context and no GPU: the rule every rank applies to the gathered records, here as a [world, 2]
+ * table of 64-bit words (value bits, global 1-based index; index 0 = that rank's shard was empty) -- TH's max over the union of the shards:
  * the first NaN wins, else the largest value, ties to the lowest global index.  B7_ERR_STATE when every shard is empty.
  * Exposed so that the rule can be checked for any world size without that many GPUs. */
 int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int64_t *best_idx1);
@@ -260,6 +272,29 @@ int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int6
  * what score:max(1) returns on the unsharded vector.  A rank whose shard is empty (no grid rows) still calls it. */
 int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offset, double *best_val,
                            int64_t *best_idx1);
+
+/* bots/abstract.lua:118 `pending, candidates = steal(pending, candidates, idx)` on a candidate set sharded across
+ * ranks: idx1_global is the nominee's 1-based index in the union of the shards (what b7_eval_nominate /
+ * b7_score_finish_global returned, or the random initial pick of bots/bayesopt.lua:90-91 drawn against the GLOBAL row
+ * count from a seed all ranks share).  *global_row_offset is this rank's offset (rows before its shard), in and out.
+ * Every rank calls it with the same idx1_global:
+ *   - the rank whose shard holds the row deletes it on the device, stably (utils/tensor.lua:158-170: later rows move up);
+ *   - ranks behind the owner get *global_row_offset - 1 back: the union has shrunk in front of them;
+ *   - row_out (nullable, d) receives the nominee's coordinates on EVERY rank: from the record of the last exchange when
+ *     idx1_global is its winner (no communication at all), otherwise by one more all-reduce in which the owner
+ *     contributes the row (the random initial trials).
+ * The removal is enqueued, not waited for: the next nomination runs behind it on the context's stream.
+ * B7_ERR_INVALID when the index lies in no shard, or the offsets overlap. */
+int b7_nominate_commit(b7_ctx *ctx, int64_t idx1_global, int64_t *global_row_offset, double *row_out);
+/* Host-only, needs no context and no GPU: the bookkeeping rule b7_nominate_commit applies, for a shard that holds global
+ * rows (offset, offset + M_local] (1-based): local_idx1 = the row to delete in this shard (0: another shard's),
+ * new_offset = offset - 1 when the deleted row lies before this shard, else offset. */
+int b7_shard_commit_rule(int64_t idx1_global, int64_t offset, int64_t M_local, int64_t *local_idx1, int64_t *new_offset);
+/* What the last exchange told this rank (all outputs nullable): world size, candidate rows held by every rank
+ * (world entries: their sum is the global row count, their prefix sums the offsets of contiguous shards), the winner's
+ * global index, owning rank and grid row (d entries).  B7_ERR_STATE when the grid has changed since. */
+int b7_exchange_info(b7_ctx *ctx, int *world, int64_t *rows_per_rank, int64_t *winner_idx1, int *winner_rank,
+                     double *winner_row);
 
 /* ---- bayesopt:eval + nominate as ONE call (bots/bayesopt.lua:56-99) --------------------------- *
  * score = (1/S) sum_s acq(model, hyp_s, X_obs, Y_obs, X_hid) over the resident data (b7_gp_set_data) and the
@@ -285,6 +320,47 @@ typedef struct {
 } b7_score_spec;
 int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset,
                      double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
+
+/* ---- one process, several GPUs: the reference's single-process trial loop over a sharded grid ----------------- *
+ * The reference is ONE LuaJIT process (bots/abstract.lua:155-169); a group lets that one process drive n GPUs, so the
+ * trial loop, Torch's RNG stream and the single evaluation of the user's objective per trial (bots/abstract.lua:124)
+ * stay as they are.  Member r is a b7_ctx on device_ids[r] holding candidate rows (offset_r, offset_r + M_r] of the grid
+ * (contiguous, near-equal shards: the first M % n members hold one row more) and a full copy of the observations.
+ * b7_group_eval_nominate enqueues fit + K* + posterior + score on every member's stream without waiting in between,
+ * combines the members' exchange records -- ONE grouped ncclAllReduce over xGMI when the devices are distinct
+ * (ncclCommInitAll), a merge on the host when members share a device (RCCL refuses that; it is how the sharding is
+ * exercised on a one-GPU machine) or B7_GROUP_EXCHANGE=host is set -- and waits once per member.  Results are those of
+ * the unsharded calls, bit for bit.  A member's grid must only be changed through the group. */
+typedef struct b7_group b7_group;
+int b7_group_create(b7_group **out, int n, const int *device_ids);   /* device ids may repeat (virtual ranks) */
+void b7_group_destroy(b7_group *g);
+const char *b7_group_last_error(const b7_group *g);
+int b7_group_info(b7_group *g, int *n, int *uses_rccl);
+/* Member r, e.g. for model:sample_hypers' density evaluations (b7_gp_fit_hyp / b7_gp_nll_batch on member 0) or
+ * b7_profile_*; owned by the group. */
+b7_ctx *b7_group_ctx(b7_group *g, int rank);
+int b7_group_set_workspace(b7_group *g, int64_t bytes);
+int b7_group_gp_set_opts(b7_group *g, const b7_gp_opts *opts);
+/* b7_grid_sobol / _random / _upload for the whole grid: every member generates (receives) its shard; one-sided maps use
+ * the column extremes of the union. */
+int b7_group_grid_sobol(b7_group *g, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes);
+int b7_group_grid_random(b7_group *g, int64_t size, int dims, uint64_t seed, const double *mins, const double *maxes);
+int b7_group_grid_onesided(b7_group *g, const double *mins, const double *maxes);
+int b7_group_grid_upload(b7_group *g, const double *X_hid, int64_t M, int d);
+/* Rows of the union, its dims, and the members' offsets (n + 1 entries: offsets[n] = M_global); all nullable. */
+int b7_group_grid_shape(b7_group *g, int64_t *M_global, int *d, int64_t *offsets);
+int b7_group_grid_download(b7_group *g, int64_t row0 /*0-based, in the union*/, int64_t rows, double *out_host);
+/* utils.tensor.remove / steal with an index tensor on the union (indices 1-based against the union before the call). */
+int b7_group_grid_remove_rows(b7_group *g, const int64_t *idx1, int64_t n, double *rows_out);
+/* b7_gp_set_data on every member. */
+int b7_group_gp_set_data(b7_group *g, const double *X_obs, const double *Y_obs, int N, int d, int ycols);
+/* b7_eval_nominate over the union: best_idx1 is 1-based in the union. */
+int b7_group_eval_nominate(b7_group *g, int S, const b7_hyp *hyps, const b7_score_spec *spec, double *best_val,
+                           int64_t *best_idx1, double *jitter_out, int *info_out);
+/* b7_nominate_commit over the union: the nominee's coordinates (row_out, nullable, d) and its stable deletion on the
+ * member that holds it.  When idx1_global is the winner of the last b7_group_eval_nominate the row comes from the
+ * exchange record and nothing is copied or waited for. */
+int b7_group_nominate_commit(b7_group *g, int64_t idx1_global, double *row_out);
 
 /* EI.compute / conf_bound.compute / max on caller-provided host vectors (M x c mean, M var). */
 int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff,

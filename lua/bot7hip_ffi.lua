@@ -22,6 +22,8 @@ int b7_set_workspace(b7_ctx *ctx, int64_t bytes);
 int b7_grid_sobol(b7_ctx *ctx, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes, double *out_host);
 int b7_sobol_direction_numbers(int dims, uint32_t *out);
 int b7_grid_random(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins, const double *maxes, double *out_host);
+int b7_grid_colrange(b7_ctx *ctx, double *col_min, double *col_max);
+int b7_grid_apply_onesided(b7_ctx *ctx, const double *mins, const double *maxes, const double *col_ext);
 int b7_grid_upload(b7_ctx *ctx, const double *X_hid, int64_t M, int d);
 int b7_grid_download(b7_ctx *ctx, int64_t row0 , int64_t rows, double *out_host);
 int b7_grid_shape(b7_ctx *ctx, int64_t *M, int *d);
@@ -59,8 +61,29 @@ int b7_comm_destroy(b7_ctx *ctx);
 int b7_comm_allreduce_f64(b7_ctx *ctx, double *inout, int n, int op);
 int b7_comm_pick_winner(const uint64_t *table, int world, double *best_val, int64_t *best_idx1);
 int b7_score_finish_global(b7_ctx *ctx, double divisor, int64_t global_row_offset, double *best_val, int64_t *best_idx1);
+int b7_nominate_commit(b7_ctx *ctx, int64_t idx1_global, int64_t *global_row_offset, double *row_out);
+int b7_shard_commit_rule(int64_t idx1_global, int64_t offset, int64_t M_local, int64_t *local_idx1, int64_t *new_offset);
+int b7_exchange_info(b7_ctx *ctx, int *world, int64_t *rows_per_rank, int64_t *winner_idx1, int *winner_rank, double *winner_row);
 typedef struct { int kind; double tradeoff; int upper; double sign; const double *fmin; } b7_score_spec;
 int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset, double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
+typedef struct b7_group b7_group;
+int b7_group_create(b7_group **out, int n, const int *device_ids);
+void b7_group_destroy(b7_group *g);
+const char *b7_group_last_error(const b7_group *g);
+int b7_group_info(b7_group *g, int *n, int *uses_rccl);
+b7_ctx *b7_group_ctx(b7_group *g, int rank);
+int b7_group_set_workspace(b7_group *g, int64_t bytes);
+int b7_group_gp_set_opts(b7_group *g, const b7_gp_opts *opts);
+int b7_group_grid_sobol(b7_group *g, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes);
+int b7_group_grid_random(b7_group *g, int64_t size, int dims, uint64_t seed, const double *mins, const double *maxes);
+int b7_group_grid_onesided(b7_group *g, const double *mins, const double *maxes);
+int b7_group_grid_upload(b7_group *g, const double *X_hid, int64_t M, int d);
+int b7_group_grid_shape(b7_group *g, int64_t *M_global, int *d, int64_t *offsets);
+int b7_group_grid_download(b7_group *g, int64_t row0 , int64_t rows, double *out_host);
+int b7_group_grid_remove_rows(b7_group *g, const int64_t *idx1, int64_t n, double *rows_out);
+int b7_group_gp_set_data(b7_group *g, const double *X_obs, const double *Y_obs, int N, int d, int ycols);
+int b7_group_eval_nominate(b7_group *g, int S, const b7_hyp *hyps, const b7_score_spec *spec, double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
+int b7_group_nominate_commit(b7_group *g, int64_t idx1_global, double *row_out);
 int b7_ei_compute(b7_ctx *ctx, const double *mean, const double *var, const double *fmin, double tradeoff, int64_t M, int c, double *out);
 int b7_cb_compute(b7_ctx *ctx, const double *mean, const double *var, double tradeoff, int upper, double sign, int64_t M, int c, double *out);
 int b7_argmax(b7_ctx *ctx, const double *scores, int64_t M, double *best_val, int64_t *best_idx1);
@@ -110,6 +133,32 @@ function M.check(rc)
   return rc
 end
 
+-- ---- one LuaJIT process, several GPUs ------------------------------------------------------------------------------
+-- The reference is a single process (bots/abstract.lua:155-169).  M.use_group{0,1,...,7} turns this process's context into
+-- a GROUP of contexts, one per listed device (b7_group_*): the candidate grid is sharded over them, the observations go to
+-- all of them, bots_bayesopt_hip's nominate runs bayesopt:eval on every GPU at once with one exchange for the winner.  The
+-- driver's own bookkeeping (self.candidates as a host tensor, steal, pending, observed, the ONE objective evaluation per
+-- trial, Torch's RNG stream) stays exactly as the reference has it.  Call before any grid is generated.
+-- M.ctx becomes member 0 (the sampler's likelihood evaluations run there).
+M.group = nil
+function M.use_group(device_ids)
+  assert(M.group == nil, 'bot7hip: a group is already in use')
+  local n   = #device_ids
+  local ids = ffi.new('int[?]', n)
+  for i = 1, n do ids[i-1] = device_ids[i] end
+  local gp = ffi.new('b7_group*[1]')
+  if C.b7_group_create(gp, n, ids) ~= 0 then error('bot7hip: ' .. ffi.string(C.b7_last_error(nil))) end
+  M.group = ffi.gc(gp[0], C.b7_group_destroy)
+  M.solo  = M.ctx                       -- keep the stand-alone context alive (its finaliser would run otherwise)
+  M.ctx   = C.b7_group_ctx(M.group, 0)  -- owned by the group: no finaliser
+  M.forget_resident()
+  return n
+end
+function M.gcheck(rc)
+  if rc ~= 0 then error('bot7hip(' .. rc .. '): ' .. ffi.string(C.b7_group_last_error(M.group)), 2) end
+  return rc
+end
+
 -- DoubleTensor -> contiguous DoubleTensor whose storage the C call may read.  The CALLER keeps the returned tensor
 -- in a local until the call has returned (t:contiguous() of a non-contiguous t is a temporary that LuaJIT may
 -- otherwise collect between the pointer being taken and the call being made) and passes torch.data(c).
@@ -132,9 +181,13 @@ function M.is_resident(t)
   return r ~= nil and torch.isTensor(t) and t:dim() == 2 and t:isContiguous() and r.rows == t:size(1)
          and r.cols == t:size(2) and r.ptr == torch.data(t)
 end
+-- resident on M.ctx itself as ONE grid (what b7_gp_predict / b7_score_* over "the grid" mean): never so with a group,
+-- where M.ctx holds a shard
+function M.is_resident_on_ctx(t) return M.group == nil and M.is_resident(t) end
 function M.upload_grid(X_hid)
   local X = M.pin(X_hid)
-  M.check(C.b7_grid_upload(M.ctx, M.data(X), X:size(1), X:size(2)))
+  if M.group then M.gcheck(C.b7_group_grid_upload(M.group, M.data(X), X:size(1), X:size(2)))
+  else M.check(C.b7_grid_upload(M.ctx, M.data(X), X:size(1), X:size(2))) end
   if X_hid:isContiguous() then M.set_resident(X_hid) else M.forget_resident() end
 end
 
@@ -151,11 +204,19 @@ function M.install_steal_hook()
     local hook = M.is_resident(src) and (axis_s or 1) == 1
     local res2, src2 = M._orig_steal(res, src, idx, axis_r, axis_s)
     if hook then
+      -- idx indexes `src`, the driver's host tensor: the WHOLE candidate set.  Without a group that is the grid on M.ctx;
+      -- with one it is the union of the members' shards, and the group maps it to (member, local row) itself.
       local list = torch.isTensor(idx) and idx:long():view(-1) or torch.LongTensor{idx}
       local n    = list:nElement()
       local arr  = ffi.new('int64_t[?]', n)
       for i = 1, n do arr[i-1] = list[i] end
-      M.check(C.b7_grid_remove_rows(M.ctx, arr, n, nil))
+      if M.group and n == 1 then
+        M.gcheck(C.b7_group_nominate_commit(M.group, arr[0], nil))   -- bots/abstract.lua:118: the nominee of this trial
+      elseif M.group then
+        M.gcheck(C.b7_group_grid_remove_rows(M.group, arr, n, nil))
+      else
+        M.check(C.b7_grid_remove_rows(M.ctx, arr, n, nil))
+      end
       if src2 ~= nil then M.set_resident(src2) else M.forget_resident() end
     end
     return res2, src2

@@ -5,14 +5,22 @@ ncclAllReduce over xGMI, csrc/comm.hip).  Mirrors bot7_amd/dist.py + the communi
 
     local D = require('bot7hip.dist_hip')
     D.init()                                   -- RANK / WORLD_SIZE from the environment, id through B7_COMM_ID_FILE
-    local lo, hi = D.shard_range(M_global)     -- this rank's rows [lo, hi) (0-based, half open)
+    local lo, hi = D.shard_range(M_global)     -- this rank's rows [lo, hi) (0-based, half open); D.M_global = M_global
     grid = bot7.grids.sobol_hip{size = hi - lo, dims = d, skip = 1 + lo, mins = mins, maxes = maxes}()
-    ... per hyper sample: model:predict_device(...), b7_score_ei / _cb (local accumulator) ...
-    local value, idx = D.nominate(nSamples)    -- bots/bayesopt.lua:79 score:div + :96 score:max(1), over ALL ranks
+    bot  = bot7.bots.bayesopt_hip(objective, hypers, config, {candidates = grid})   -- every rank, in lock step
+    bot:run_experiment()
+
+Lock step means: every rank runs the same driver on the same observations with Torch's RNG seeded identically
+(torch.manualSeed(s) on all ranks before the bot is built), so the hyper samples and the random initial picks agree, and
+every rank evaluates the objective on the nominee (bots/abstract.lua:124) -- world times per trial.  When that is not
+acceptable (an expensive black box), use ONE process with a group of GPUs instead: bot7hip_ffi.use_group (INTEGRATION.md 4).
+
+Index convention: bot:nominate returns the nominee's 1-based index in the UNION of the shards; D.commit(idx) is the sharded
+form of bots/abstract.lua:118's steal and is the only consumer of that index (bots_bayesopt_hip.lua:run_trial).
 --]]
 local ffi = require('ffi')
 local hip = require('bot7hip.bot7hip_ffi')
-local D   = {rank = 0, world = 1, lo = 0}
+local D   = {rank = 0, world = 1, lo = 0, M_global = nil}
 
 -- rank 0 makes the 128-byte id (ncclGetUniqueId) and publishes it through a file every rank can read (a shared
 -- /dev/shm path on one node); the others poll for it.  Any other channel (MPI, a socket) does as well.
@@ -46,8 +54,24 @@ function D.shard_range(M, rank, world)
   local rank, world = rank or D.rank, world or D.world
   local base, extra = math.floor(M / world), M % world
   local lo = rank * base + math.min(rank, extra)
-  D.lo = lo
+  D.lo, D.M_global = lo, M
   return lo, lo + base + ((rank < extra) and 1 or 0)
+end
+
+-- bots/abstract.lua:118 `pending, candidates = steal(pending, candidates, idx)` with the candidates sharded over ranks:
+-- idx_global is 1-based in the union.  Returns the nominee's coordinates (a d-vector, the same on every rank) and the
+-- 1-based LOCAL index of the deleted row on the rank that held it (0 elsewhere).  The library deletes the row on the
+-- owner's device and moves D.lo on the ranks behind it (b7_nominate_commit); D.M_global shrinks by one everywhere.
+function D.commit(idx_global, d)
+  local Mloc, dd = ffi.new('int64_t[1]'), ffi.new('int[1]')
+  hip.check(hip.C.b7_grid_shape(hip.ctx, Mloc, dd))
+  local loc, off = ffi.new('int64_t[1]'), ffi.new('int64_t[1]', D.lo)
+  hip.check(hip.C.b7_shard_commit_rule(idx_global, D.lo, Mloc[0], loc, nil))
+  local row = torch.DoubleTensor(d or dd[0])
+  hip.check(hip.C.b7_nominate_commit(hip.ctx, idx_global, off, torch.data(row)))
+  D.lo = tonumber(off[0])
+  if D.M_global then D.M_global = D.M_global - 1 end
+  return row, tonumber(loc[0])
 end
 
 -- score:div(divisor) on this rank's accumulator, then the global first maximum: (value, 1-based GLOBAL index)

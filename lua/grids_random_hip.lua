@@ -20,16 +20,13 @@ end
 function grid:generate(config)
   local config = config or self.config
   local out    = torch.DoubleTensor(config.size, config.dims)
-  local both   = config.mins and config.maxes
-  local mins, maxes = both and hip.pin(config.mins) or nil, both and hip.pin(config.maxes) or nil
-  hip.check(hip.C.b7_grid_random(hip.ctx, config.size, config.dims, config.seed or 0, config.row_offset or 0,
-                                 hip.data(mins), hip.data(maxes), torch.data(out)))            -- :24, :27-28
-  if not both and config.mins then          -- :29-30
-    out:add(torch.add(config.mins, out:min(1)[1]):expandAs(out))
-    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
-  elseif not both and config.maxes then     -- :31-32
-    out:cmul(torch.cdiv(config.maxes, out:max(1)[1]):expandAs(out))
-    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
+  local mins, maxes = hip.pin(config.mins), hip.pin(config.maxes)            -- :27-33, one-sided maps included
+  if hip.group then
+    hip.gcheck(hip.C.b7_group_grid_random(hip.group, config.size, config.dims, config.seed or 0, hip.data(mins), hip.data(maxes)))
+    hip.gcheck(hip.C.b7_group_grid_download(hip.group, 0, config.size, torch.data(out)))
+  else
+    hip.check(hip.C.b7_grid_random(hip.ctx, config.size, config.dims, config.seed or 0, config.row_offset or 0,
+                                   hip.data(mins), hip.data(maxes), torch.data(out)))            -- :24
   end
   hip.set_resident(out)
   return out

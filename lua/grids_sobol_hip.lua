@@ -25,15 +25,14 @@ function grid:generate(config)
   local config = config or self.config
   local skip   = config.skip or 1                 -- :70 (0 is truthy in Lua: skip = 0 stays 0)
   local out    = torch.DoubleTensor(config.size, config.dims)
-  local both   = config.mins and config.maxes
-  local mins, maxes = both and hip.pin(config.mins) or nil, both and hip.pin(config.maxes) or nil
-  hip.check(hip.C.b7_grid_sobol(hip.ctx, config.size, config.dims, skip, hip.data(mins), hip.data(maxes), torch.data(out)))
-  if not both and config.mins then          -- grids/sobol.lua:82-83 (host side, rare)
-    out:add(torch.add(config.mins, out:min(1)[1]):expandAs(out))
-    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
-  elseif not both and config.maxes then     -- :84-85
-    out:cmul(torch.cdiv(config.maxes, out:max(1)[1]):expandAs(out))
-    hip.check(hip.C.b7_grid_upload(hip.ctx, torch.data(out), out:size(1), out:size(2)))
+  -- both, one or none of mins / maxes: the library applies grids/sobol.lua:79-85 as written (the one-sided maps use the
+  -- column extremes of the WHOLE grid, combined across ranks / group members inside the call)
+  local mins, maxes = hip.pin(config.mins), hip.pin(config.maxes)
+  if hip.group then
+    hip.gcheck(hip.C.b7_group_grid_sobol(hip.group, config.size, config.dims, skip, hip.data(mins), hip.data(maxes)))
+    hip.gcheck(hip.C.b7_group_grid_download(hip.group, 0, config.size, torch.data(out)))
+  else
+    hip.check(hip.C.b7_grid_sobol(hip.ctx, config.size, config.dims, skip, hip.data(mins), hip.data(maxes), torch.data(out)))
   end
   hip.set_resident(out)
   return out

@@ -49,6 +49,7 @@ function dngo:predict(X0, Y0, X1, hyp, req, skip)
   -- :155-162 (features of X0) and the fit half of :174 in one call; Z0 never leaves the device
   local X0c, Y0c = hip.pin(X0), hip.pin(Y0)
   hip.check(hip.C.b7_blr_fit_x(hip.ctx, net, hip.data(X0c), hip.data(Y0c), X0:size(1), h.alpha, h.beta, h.mean, nil))
+  assert(hip.group == nil, 'bot7hip: the DNGO head runs on one GPU (no group)')
   if not hip.is_resident(X1) then hip.upload_grid(X1) end
   hip.check(hip.C.b7_blr_basis(hip.ctx, net, nil, 0, nil))                                        -- :164-171
   local mean, var = torch.DoubleTensor(X1:size(1), 1), torch.DoubleTensor(X1:size(1))

@@ -64,21 +64,25 @@ end
 
 -- ---- fits ---------------------------------------------------------------------------------------------------------------
 -- The data go to the device once per (X_obs, Y_obs) pair: the sampler and the marginalisation loop refit the SAME
--- tensors under new hypers (bots/bayesopt.lua:68-78), so a pointer + shape match means "already resident".
+-- tensors under new hypers (bots/bayesopt.lua:68-78).
+-- keyed on the CONTENT (a copy of what was uploaded: N x (d + c) doubles, nothing next to a fit): pointers get reused by
+-- the allocator and sums collide (Y and -Y with zero sum, two responses swapped)
 local function same_data(self, X, Y)
   local k = self._data
-  return k ~= nil and k.xp == torch.data(X) and k.yp == torch.data(Y) and k.n == X:size(1) and k.d == X:size(2)
-         and k.c == Y:size(2) and k.xs == X:sum() and k.ys == Y:sum()   -- an allocator may hand the address out again
+  return k ~= nil and k.x:isSameSizeAs(X) and k.y:isSameSizeAs(Y) and k.x:equal(X) and k.y:equal(Y)
 end
 
 -- (X_obs, Y_obs) resident on the device; uploads only when they are not the pair already there.  Returns Y as N x c.
 function model:stage_data(X_obs, Y_obs)
   local X = hip.pin(X_obs)
   local Y = hip.pin(Y_obs:dim() == 1 and Y_obs:view(-1, 1) or Y_obs)
-  if not (same_data(self, X, Y) and X_obs:isContiguous() and Y_obs:isContiguous()) then
-    hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))   -- synchronous
-    self._data = {xp = torch.data(X), yp = torch.data(Y), n = X:size(1), d = X:size(2), c = Y:size(2),
-                  xs = X:sum(), ys = Y:sum()}
+  if not same_data(self, X, Y) then
+    if hip.group then   -- every member of the group refits the same observations
+      hip.gcheck(hip.C.b7_group_gp_set_data(hip.group, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))
+    else
+      hip.check(hip.C.b7_gp_set_data(hip.ctx, hip.data(X), hip.data(Y), X:size(1), X:size(2), Y:size(2)))   -- synchronous
+    end
+    self._data = {x = X:clone(), y = Y:clone()}
   end
   return Y
 end
@@ -231,6 +235,9 @@ end
 -- fit + predict leaving mean/var on the device (used by the *_hip scores)
 function model:predict_device(X_obs, Y_obs, X_hid, hyp)
   local hyp = hyp or self.hyp
+  if hip.group then   -- M.ctx holds one shard: per-sample scoring over "the grid" has no meaning on it
+    error('bot7hip: with a group of GPUs the scores run through bot7.bots.bayesopt_hip (b7_group_eval_nominate)')
+  end
   if not hip.is_resident(X_hid) then hip.upload_grid(X_hid) end
   local Y = self:stage_data(X_obs, Y_obs)
   local ls = hip.pin(hyp.lenscale_sq)
@@ -247,7 +254,7 @@ function model:predict(X_obs, Y_obs, X_hid, hyp, req)   -- scores/expected_impro
   local c    = (Y_obs:dim() == 1) and 1 or Y_obs:size(2)
   local mean, var = torch.DoubleTensor(M, c), torch.DoubleTensor(M)
   self:fit(X_obs, Y_obs, hyp or self.hyp, false)
-  if hip.is_resident(X_hid) then
+  if hip.is_resident_on_ctx(X_hid) then
     hip.check(hip.C.b7_gp_predict(hip.ctx, torch.data(mean), torch.data(var)))
   else
     local X = hip.pin(X_hid)

@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import cport, gp  # noqa: E402
-from bot7_amd import benchmarks as B  # noqa: E402
+from harness import benchmarks as B  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

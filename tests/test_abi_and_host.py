@@ -8,8 +8,9 @@ import numpy as np
 import pytest
 
 import bot7_amd
-from bot7_amd import _lib, dist
-from bot7_amd.utils import tensor as T
+from bot7_amd import _lib
+from harness import dist
+from harness import tensor as T
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -113,7 +114,7 @@ def test_pick_winner_th_semantics(orc):
 
 def test_slice_sampler_defaults_and_distribution():
     """samplers/slice.lua: defaults (:32-48) and the update itself on densities with known moments."""
-    from bot7_amd.samplers import slice_sampler
+    from harness.samplers import slice_sampler
     S = slice_sampler()
     opt = S.configure({})
     assert opt["max_step"] == 1e3 and opt["nSamples"] == 1 and opt["step_out"] is True and opt["logspace"] is True

@@ -22,7 +22,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as td
-    from bot7_amd import dist
+    from harness import dist
     from oracle import cport
     td.init_process_group("gloo", rank=rank, world_size=world)
     out = []
@@ -80,6 +80,34 @@ class _OracleCtx(object):
     def comm_info(self):
         return (0, 1)                      # no communicator: the torch.distributed exchange is used
 
+    # -- what the harness bot's trial loop calls besides (tests/test_sharded_loop.py)
+    def gp_set_data(self, X_obs, Y):
+        self.X_obs, self.Y = np.asarray(X_obs, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+
+    def grid_shape(self):
+        return self.X.shape
+
+    def grid_remove(self, idx1):           # utils.tensor.remove (utils/tensor.lua:158-170): stable deletion
+        row = self.X[idx1 - 1].copy()
+        self.X = np.delete(self.X, idx1 - 1, axis=0)
+        return row
+
+    def eval_nominate(self, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0, global_row_offset=0):
+        """The unsharded nomination (a world of one): bots/bayesopt.lua:56-99 with the oracle."""
+        for s, h in enumerate(hyps):
+            self.gp_predict_hyp(h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
+            if s == 0:
+                self.score_reset()
+            if score == "ei":
+                self.score_ei(fmin, tradeoff or 0.0)
+            else:
+                self.score_cb(1.0 if tradeoff is None else tradeoff, upper, sign)
+        v, i, _ = self.score_finish(float(len(hyps)))
+        return v, global_row_offset + i
+
+    def nominate_commit(self, idx1_global, lo):
+        return self.grid_remove(idx1_global - lo), lo
+
     def gp_predict_hyp(self, lenscale_sq, amp, noise, mean):
         f = self.gp.fit(self.X_obs, self.Y, lenscale_sq, amp, noise, mean)
         self.mu, self.var = self.gp.predict(f, self.X)
@@ -103,7 +131,7 @@ def _nominate_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as td
-    from bot7_amd import benchmarks, dist
+    from harness import benchmarks, dist
     from oracle import cport, gp
     td.init_process_group("gloo", rank=rank, world_size=world)
     d, N, M = 6, 40, 1501

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from bot7_amd import benchmarks as B
+from harness import benchmarks as B
+from harness import bots
 from conftest import make_problem
 
 pytestmark = pytest.mark.gpu
@@ -632,7 +633,7 @@ def test_bayesopt_driver_cfg1_plumbing(ctx, orc):
     """BASELINE config 1: braninhoo 2-D, GP+EI, 256-point grid, 25 trials, through the bots.bayesopt mirror;
     every nomination is re-derived with the oracle from the same observed set."""
     import bot7_amd
-    from bot7_amd import bots
+    from harness import bots
 
     class H(object):
         def __init__(self, name):
@@ -672,9 +673,12 @@ def test_full_size_metric_config_properties(ctx, orc):
     """N = 2048, d = 32 (the metric's configuration), M = 65536 + ragged tail.
     (1) bit-reproducible; (2) chunking-independent (a checksum of checksums over shards);
     (3) 0 < var <= amp; (4) a random sample of candidates agrees with the oracle to 1e-5;
-    (5) arg-max equals the arg-max of the downloaded scores with TH semantics."""
+    (5) arg-max equals the arg-max of the downloaded scores with TH semantics, and -- the pool starts at bench.SOBOL_SKIP, so
+    (0.5, ..., 0.5), ackley's exact minimum, is NOT an observation and EI is not identically zero -- the winner is a
+    candidate with positive EI that the oracle re-derives over a window of rows around it."""
+    import bench
     d, N, M = 32, 2048, 65536 + 77
-    pool = ctx.grid_sobol(M + N, d, 1)
+    pool = ctx.grid_sobol(M + N, d, bench.SOBOL_SKIP)
     step = (M + N) // N
     obs_idx = np.arange(N) * step
     mask = np.ones(M + N, dtype=bool)
@@ -715,6 +719,14 @@ def test_full_size_metric_config_properties(ctx, orc):
     # (5)
     widx, wval = orc.c.argmax_first(ei)
     assert idx == widx and val == wval
+    assert val > 0.0 and np.count_nonzero(ei == val) == 1, "the arg-max is a tie-break, not a winner"
+    w0 = int(min(max(0, idx - 1 - 2048), M - 4096))
+    mu_w, var_w = orc.gp.predict(f, X_hid[w0:w0 + 4096])
+    ei_w = orc.c.ei(mu_w, var_w, [float(Y.min())])
+    oidx, oval = orc.c.argmax_first(ei_w)
+    top2 = np.partition(ei_w, -2)[-2:]
+    print("full-size winner %d, EI %.3e, oracle top-2 gap in its window %.3e, |EI - oracle| %.1e" % (idx, val, top2[1] - top2[0], abs(val - oval)))
+    assert oidx + w0 == idx and abs(val - oval) <= 1e-7 * max(abs(oval), 1e-300) + 1e-3 * (top2[1] - top2[0])
 
 
 # ---- hyper sampling: slice sampler on the host, every density evaluation a device fit ---------------
@@ -764,7 +776,7 @@ def test_bayesopt_with_sampled_hypers_runs(ctx, orc):
     cfg = {"bot": {"verbose": 0, "budget": 8, "nInitial": 3, "nSamples": 3, "seed": 2},
            "grid": {"type": "sobol", "size": 400, "dims": 2}, "score": {"type": "confidence_bound"},
            "model": {"type": "gp_regressor", "sample": True, "nBurnin": 2, "seed": 5}}
-    bot = bot7_amd.bots.bayesopt(B.braninhoo, [H("x1"), H("x2")], cfg)
+    bot = bots.bayesopt(B.braninhoo, [H("x1"), H("x2")], cfg)
     bot.model._ctx = ctx
     bot.candidates = bot7_amd.grids.sobol(bot.config["grid"], context=ctx)()
     best = bot.run_experiment()
@@ -895,7 +907,7 @@ def test_dngo_model_in_bayesopt_loop(ctx, orc):
            "model": {"type": "dngo", "network": {"weights": W, "biases": b, "activation": "Tanh"}, "alpha": 1.0}}
     grid = bot7_amd.grids.sobol(dict(cfg["grid"], mins=np.zeros(6), maxes=np.ones(6)), context=ctx)()
     model = bot7_amd.models.dngo(cfg["model"], context=ctx)
-    bot = bot7_amd.bots.bayesopt(B.hartmann6, [H("x%d" % i) for i in range(6)], cfg,
+    bot = bots.bayesopt(B.hartmann6, [H("x%d" % i) for i in range(6)], cfg,
                                  cache={"candidates": grid, "model": model})
     for t in range(1, 8):
         cand = np.asarray(bot.candidates).copy()
@@ -1769,7 +1781,7 @@ def test_lockstep_chains_follow_the_single_chain_sampler_and_batch_their_densiti
     assert batches < evals / 3, "the chains' requests were not batched (%d batches for %d evaluations)" % (batches, evals)
     # the same update, chain by chain, through single fits
     ref = bot7_amd.models.gp_regressor({"sample": True, "seed": 3}, context=ctx)
-    from bot7_amd.samplers import slice_sampler
+    from harness.samplers import slice_sampler
     S = slice_sampler()
     lo, hi = model._bounds(X_obs, Y)
     t0 = time.perf_counter()

@@ -155,3 +155,58 @@ def test_lua_blocks_and_brackets_balance():
         assert bal == 0, "%s: %d block(s) left open" % (f, bal)
         for a, b in ("()", "{}", "[]"):
             assert src.count(a) == src.count(b), "%s: unbalanced %s%s" % (f, a, b)
+
+
+def _function_body(src, header):
+    """Text of the Lua function whose header line starts with `header`, up to the `end` in column 0 that closes it."""
+    i = src.index(header)
+    j = src.index("\nend", i)
+    return src[i:j]
+
+
+def test_indices_stay_in_the_coordinate_system_of_their_consumer():
+    """The class of bug VERDICT r2 found (nominate returned an index into the UNION of the shards, the parent's run_trial used
+    it on the LOCAL shard): for every index a shim hands back to the driver, check who consumes it and in which coordinates.
+
+    one rank / a group of GPUs   self.candidates is the whole set -> nominate's index is an index into it -> the parent's
+                                 bots/abstract.lua:118 may use it (the steal hook forwards the SAME index to the library,
+                                 which maps it to a member and a local row itself)
+    one process per GPU          self.candidates is a shard -> the index is in union coordinates -> only dist_hip.commit may
+                                 consume it; the parent's run_trial must not run"""
+    bt = strip_lua_comments(open(os.path.join(LUA, "bots_bayesopt_hip.lua")).read())
+    dh = strip_lua_comments(open(os.path.join(LUA, "dist_hip.lua")).read())
+    ffi = strip_lua_comments(open(os.path.join(LUA, "bot7hip_ffi.lua")).read())
+    nominate = _function_body(bt, "function bot:nominate(")
+    run_trial = _function_body(bt, "function bot:run_trial(")
+    # (1) producers: the union-coordinate index comes from b7_eval_nominate with this rank's offset, the whole-set index from
+    #     the group call (no offset argument at all)
+    assert re.search(r"b7_eval_nominate\(hip\.ctx, S, hyps, spec, D\.lo,", nominate)
+    assert re.search(r"b7_group_eval_nominate\(hip\.group, S, hyps, spec, v, i,", nominate)
+    # (2) the random initial pick is drawn in the same coordinates as the model-based one: union rows when sharded
+    assert re.search(r"\(D\.world > 1\) and assert\(D\.M_global", nominate) and "candidates:size(1)" in nominate
+    # (3) consumer, one process per GPU: run_trial is overridden, leaves to the parent ONLY for one rank, hands the index to
+    #     D.commit and never indexes the local shard with it
+    assert re.search(r"if D\.world == 1 then return parent\.run_trial\(self\) end", run_trial)
+    m = re.search(r"local idx = self:nominate\(\)(.*?)D\.commit\((\w+),", run_trial, flags=re.S)
+    assert m and "steal" not in m.group(1) and "self.candidates:" not in m.group(1)
+    after = run_trial[m.end():]
+    assert "utils.tensor.steal(self.pending, self.candidates" not in run_trial      # the parent's line 118, union index on a shard
+    # the only index applied to the local shard is the LOCAL one D.commit returned
+    assert re.search(r"local row, loc = D\.commit\(", run_trial)
+    assert re.search(r"utils\.tensor\.remove\(self\.candidates, torch\.LongTensor\{loc\}\)", after)
+    # (4) D.commit: the library gets the union index and this rank's offset in/out; the local index is derived with the
+    #     library's own rule from the same three numbers; D.lo is written back; the union's row count shrinks
+    commit = _function_body(dh, "function D.commit(")
+    assert re.search(r"b7_shard_commit_rule\(idx_global, D\.lo, Mloc\[0\], loc, nil\)", commit)
+    assert re.search(r"b7_nominate_commit\(hip\.ctx, idx_global, off, torch\.data\(row\)\)", commit)
+    assert re.search(r"ffi\.new\('int64_t\[1\]', D\.lo\)", commit) and "D.lo = tonumber(off[0])" in commit
+    assert "D.M_global = D.M_global - 1" in commit
+    # (5) consumer, group: the hook fires only for the resident host tensor (= the whole set) and forwards its index
+    hook = ffi[ffi.index("function M.install_steal_hook()"):]
+    assert "M.is_resident(src)" in hook and re.search(r"b7_group_nominate_commit\(M\.group, arr\[0\], nil\)", hook)
+    assert re.search(r"b7_group_grid_remove_rows\(M\.group, arr, n, nil\)", hook)
+    # (6) what "resident" means with a group: never the grid of M.ctx alone
+    assert "function M.is_resident_on_ctx(t) return M.group == nil and M.is_resident(t) end" in ffi
+    gp = strip_lua_comments(open(os.path.join(LUA, "models_gp_hip.lua")).read())
+    predict = _function_body(gp, "function model:predict(")
+    assert "hip.is_resident_on_ctx(X_hid)" in predict and "hip.is_resident(X_hid)" not in predict

@@ -8,7 +8,7 @@ import mpmath
 import numpy as np
 import pytest
 
-from bot7_amd import benchmarks as B
+from harness import benchmarks as B
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

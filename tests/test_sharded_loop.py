@@ -1,0 +1,272 @@
+"""The reference's trial loop (bots/abstract.lua:112-152) on a candidate set sharded across GPUs (last bullet):
+nomination over the union, the nominee's coordinates on every rank, stable deletion on the owner, offset shift behind it.
+
+CPU (`-m "not gpu"`): the library's host-only bookkeeping rule against np.delete on the union; world-2 / world-3 gloo runs
+of >= 6 trials of BASELINE cfg1 (braninhoo, 256-point grid) with the oracle standing in for the device, which must reproduce
+the unsharded run's nominees, candidate sets and best.
+GPU (`-m gpu`): the same through the product -- a single-process group of 2 and 3 virtual ranks on the one GPU
+(b7_group_*: the exchange records are merged on the host, RCCL refuses two ranks on one device), a group of one over RCCL,
+and b7_nominate_commit on a plain context."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class H(object):
+    def __init__(self, name):
+        self.name, self.min, self.max, self.size = name, 0.0, 1.0, 1
+
+
+# ---- the bookkeeping rule (host-only export of the library) ----------------------------------------------------------
+def test_shard_commit_rule_is_stable_deletion_on_the_union():
+    from bot7_amd import _lib
+    from harness import dist
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 5, 8):
+        M = 97
+        union = np.arange(M)                      # row ids; the union is the concatenation of the shards in rank order
+        shards = [union[slice(*dist.shard_range(M, r, world))].copy() for r in range(world)]
+        offs = [dist.shard_range(M, r, world)[0] for r in range(world)]
+        for _ in range(60):
+            idx = int(rng.integers(1, union.size + 1))
+            owners = 0
+            for r in range(world):
+                loc, new_off = _lib.shard_commit_rule(idx, offs[r], shards[r].size)
+                if loc:
+                    owners += 1
+                    assert shards[r][loc - 1] == union[idx - 1]
+                    shards[r] = np.delete(shards[r], loc - 1)
+                offs[r] = new_off
+            assert owners == 1
+            union = np.delete(union, idx - 1)     # utils.tensor.remove on the unsharded tensor (utils/tensor.lua:158-170)
+            assert np.array_equal(np.concatenate(shards), union)
+            assert offs == list(np.cumsum([0] + [s.size for s in shards[:-1]]))
+    with pytest.raises(_lib.Bot7HipError):
+        _lib.shard_commit_rule(0, 0, 5)
+
+
+# ---- gloo rehearsal on CPU: the oracle stands in for the device ---------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg1_grid():
+    """BASELINE cfg1's 256-point uniform grid on [0,1]^2 (Torch's MT stream is not in the tree: a fixed numpy stream)."""
+    return np.random.default_rng(11).random((256, 2))
+
+
+def _run_bot(cand, model_ctx, trials, nSamples=2):
+    """`trials` trials of the harness bot (harness/bots: the reference's run_trial, statement for statement) over the given
+    candidate set -> (nominees, responses, best)."""
+    import bot7_amd
+    from harness import benchmarks, bots
+    cfg = {"bot": {"verbose": 0, "budget": trials, "nInitial": 2, "nSamples": nSamples, "seed": 4},
+           "grid": {"type": "random", "size": 256, "dims": 2}, "score": {"type": "expected_improvement"}}
+    model = bot7_amd.models.gp_regressor({}, context=model_ctx)
+    bot = bots.bayesopt(benchmarks.braninhoo, [H("x1"), H("x2")], cfg, cache={"candidates": cand, "model": model})
+    xs = []
+    for _ in range(trials):
+        x, y = bot.run_trial()
+        bot.update_best(x, y)
+        xs.append(np.array(x, dtype=np.float64).ravel())
+    return np.stack(xs), bot.responses.copy(), (bot.best["t"], np.array(bot.best["x"]).ravel(), float(np.ravel(bot.best["y"])[0]))
+
+
+def _loop_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as td
+    from harness import dist
+    from test_dist_gloo import _OracleCtx
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    grid, trials = _cfg1_grid(), 8
+    # the unsharded run (every rank computes it for itself)
+    whole = _OracleCtx(None, None, grid.copy())
+    one = dist.ShardedScorer(whole, grid.shape[0], 0, 1)
+    xs1, ys1, best1 = _run_bot(one, whole, trials)
+    # the sharded run: this rank owns rows [lo, hi)
+    lo, hi = dist.shard_range(grid.shape[0], rank, world)
+    mine = _OracleCtx(None, None, grid[lo:hi].copy())
+    shard = dist.ShardedScorer(mine, grid.shape[0], rank, world)
+    xs, ys, best = _run_bot(shard, mine, trials)
+    # the union of the shards after the run, in rank order, against the unsharded candidate set
+    import torch
+    parts = [None] * world
+    td.all_gather_object(parts, mine.X)
+    ok = {"nominees": bool(np.array_equal(xs, xs1)), "responses": bool(np.array_equal(ys, ys1)),
+          "best": best[0] == best1[0] and np.array_equal(best[1], best1[1]) and best[2] == best1[2],
+          "candidates": bool(np.array_equal(np.concatenate(parts), whole.X)),
+          "offset": shard.lo == sum(p.shape[0] for p in parts[:rank]), "rows": whole.X.shape[0] == grid.shape[0] - trials}
+    td.barrier()
+    td.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_trial_loop_gloo_reproduces_the_unsharded_run(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok in results:
+        assert all(ok.values()), "rank %d: sharded trial loop differs from the unsharded one: %s" % (rank, ok)
+
+
+# ---- the product: single-process groups of virtual ranks on the one GPU -------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample", [False, True])
+def test_group_trial_loop_reproduces_the_single_context_run(ctx, sample):
+    """>= 6 trials of cfg1 (braninhoo, 256-point grid, nInitial = 2) through b7_group_eval_nominate + b7_group_nominate_commit
+    with the grid sharded over 2 and 3 members, against the same loop on one context: nominees, responses, best and the
+    candidate set after every trial are identical, bit for bit.  With sample = True the hypers come from the slice sampler
+    (three per nomination), so the marginalisation runs sharded too."""
+    import bot7_amd
+    from harness import benchmarks, bots, dist
+    grid, trials = _cfg1_grid(), 9
+    mcfg = {"sample": True, "nBurnin": 1, "seed": 5} if sample else {}
+
+    def run(cand, model_ctx, after_trial):
+        cfg = {"bot": {"verbose": 0, "budget": trials, "nInitial": 2, "nSamples": 3, "seed": 4},
+               "grid": {"type": "random", "size": 256, "dims": 2}, "score": {"type": "expected_improvement"}}
+        model = bot7_amd.models.gp_regressor(dict(mcfg), context=model_ctx)
+        bot = bots.bayesopt(benchmarks.braninhoo, [H("x1"), H("x2")], cfg, cache={"candidates": cand, "model": model})
+        xs, sets = [], []
+        for _ in range(trials):
+            x, y = bot.run_trial()
+            bot.update_best(x, y)
+            xs.append(np.array(x, dtype=np.float64).ravel())
+            sets.append(after_trial())
+        return np.stack(xs), bot.responses.copy(), (bot.best["t"], float(np.ravel(bot.best["y"])[0])), sets
+
+    ctx.grid_upload(grid)
+    one = dist.ShardedScorer(ctx, grid.shape[0], 0, 1)          # a world of one: b7_eval_nominate + b7_nominate_commit
+    xs1, ys1, best1, sets1 = run(one, ctx, ctx.grid_download)
+    host = grid.copy()
+    for t, x in enumerate(xs1):                                  # the unsharded bookkeeping, on the host
+        row = np.where((host == x).all(axis=1))[0][0]
+        host = np.delete(host, row, axis=0)
+        assert np.array_equal(sets1[t], host)
+    for n in (2, 3):
+        g = bot7_amd.Group([0] * n)
+        assert g.info() == {"n": n, "uses_rccl": False}
+        g.grid_upload(grid)
+        xs, ys, best, sets = run(dist.GroupCandidates(g), g.members[0], g.grid_download)
+        assert np.array_equal(xs, xs1), "group of %d nominated differently" % n
+        assert np.array_equal(ys, ys1) and best == best1
+        for a, b in zip(sets, sets1):
+            assert np.array_equal(a, b)
+        M, d, offs = g.grid_shape()
+        assert M == grid.shape[0] - trials and offs[-1] == M and list(offs) == sorted(offs)
+        g.close()
+
+
+@pytest.mark.gpu
+def test_group_nomination_matches_one_context_bit_for_bit(ctx, orc):
+    """hartmann6, N = 300, 50 001 Sobol candidates, S = 3, EI and -LCB: the winner (value bits and index) of a group of 1 (the
+    exchange goes through RCCL: ncclCommInitAll + grouped all-reduce), 2, 3 and 5 virtual ranks equals the single context's;
+    the committed row is the grid row; an observation set that needs the jitter schedule takes the per-sample redo on every
+    member and still agrees."""
+    import bot7_amd
+    from harness import benchmarks
+    d, N, M = 6, 300, 50001
+    pool = orc.c.sobol(M + N, d, 2)
+    X_obs, X_hid = pool[:N].copy(), pool[N:].copy()
+    Y = benchmarks.hartmann6(X_obs)
+    amp = float(np.var(Y))
+    hyps = [dict(lenscale_sq=np.full(d, d / 8.0) * (1 + 0.3 * s), amp=amp, noise=1e-4 * amp, mean=float(np.mean(Y))) for s in range(3)]
+    Xdup = np.concatenate([X_obs, X_obs[:7]])                    # duplicated rows + no noise: the plain attempt fails
+    Ydup = np.concatenate([Y, Y[:7]])
+    hard = [dict(h, noise=0.0) for h in hyps[:2]]
+    specs = ({"score": "ei", "fmin": [float(Y.min())]}, {"score": "cb"})
+    ctx.grid_upload(X_hid)
+    want = []
+    ctx.gp_set_data(X_obs, Y)
+    for sp in specs:
+        want.append(ctx.eval_nominate(hyps, **sp))
+    ctx.gp_set_data(Xdup, Ydup)
+    wv, wi, rep = ctx.eval_nominate(hard, want_report=True, **specs[0])
+    assert (rep["jitter"] > 0).all(), "the hard case was meant to need the jitter schedule"
+    for n in (1, 2, 3, 5):
+        g = bot7_amd.Group([0] * n)
+        assert g.info()["uses_rccl"] == (n == 1)
+        g.grid_sobol(M, d, 2 + N)                                # every member generates its own shard
+        assert np.array_equal(g.grid_download(), X_hid)
+        g.gp_set_data(X_obs, Y)
+        for sp, w in zip(specs, want):
+            v, i = g.eval_nominate(hyps, **sp)
+            assert (v, i) == w, "group of %d: %r != %r" % (n, (v, i), w)
+        row = g.nominate_commit(i)                               # the last winner: the row comes out of the exchange record
+        assert np.array_equal(row, X_hid[i - 1])
+        assert np.array_equal(g.grid_download(), np.delete(X_hid, i - 1, axis=0))
+        row2 = g.nominate_commit(17)                             # not a winner: read from the owner's grid
+        assert np.array_equal(row2, np.delete(X_hid, i - 1, axis=0)[16])
+        with pytest.raises(bot7_amd.Bot7HipError):
+            g.nominate_commit(M)                                 # M - 2 rows are left
+        with pytest.raises(bot7_amd.Bot7HipError):
+            g.members[0].grid_upload(X_hid[:10])                 # a member's grid only changes through the group
+        g.grid_upload(X_hid)
+        g.gp_set_data(Xdup, Ydup)
+        v, i, r = g.eval_nominate(hard, want_report=True, **specs[0])
+        assert (v, i) == (wv, wi) and np.array_equal(r["jitter"], rep["jitter"]) and np.array_equal(r["info"], rep["info"])
+        g.close()
+
+
+@pytest.mark.gpu
+def test_nominate_commit_on_a_plain_context_and_a_world_of_one(ctx, orc):
+    """b7_nominate_commit without a communicator and with a world-of-one RCCL communicator: the winner's row comes from the
+    exchange record (equal to the grid row), any other index is read from the grid; the row is deleted stably; offsets
+    follow the rule; the exchange record reports the shard's rows."""
+    import bot7_amd
+    from bot7_amd import _lib
+    from harness import benchmarks
+    d, N, M = 6, 64, 3000
+    pool = orc.c.sobol(M + N, d, 2)
+    X_obs, X_hid = pool[:N].copy(), pool[N:].copy()
+    Y = benchmarks.hartmann6(X_obs)
+    amp = float(np.var(Y))
+    hyp = dict(lenscale_sq=np.full(d, d / 8.0), amp=amp, noise=1e-4 * amp, mean=float(np.mean(Y)))
+    for with_comm in (False, True):
+        c = bot7_amd.Context(0)
+        if with_comm:
+            c.comm_init(0, 1, _lib.comm_unique_id())
+        c.grid_upload(X_hid)
+        c.gp_set_data(X_obs, Y)
+        off = 1000                                              # pretend 1000 rows of other shards lie before this one
+        v, i = c.eval_nominate([hyp], score="ei", fmin=[float(Y.min())], global_row_offset=off)
+        info = c.exchange_info()
+        assert info["world"] == 1 and list(info["rows"]) == [M] and info["winner_idx1"] == i and info["winner_rank"] == 0
+        assert np.array_equal(info["winner_row"], X_hid[i - off - 1])
+        row, new_off = c.nominate_commit(i, off)
+        assert new_off == off and np.array_equal(row, X_hid[i - off - 1])
+        left = np.delete(X_hid, i - off - 1, axis=0)
+        assert np.array_equal(c.grid_download(), left)
+        with pytest.raises(bot7_amd.Bot7HipError):
+            c.exchange_info()                                   # the grid has changed since
+        row, new_off = c.nominate_commit(off + 5, off)          # a random initial pick: no exchange record to take it from
+        assert np.array_equal(row, left[4]) and new_off == off
+        left = np.delete(left, 4, axis=0)
+        assert np.array_equal(c.grid_download(), left)
+        if not with_comm:
+            row, new_off = (None, None)
+            with pytest.raises(bot7_amd.Bot7HipError):
+                c.nominate_commit(off, off)                     # the row before this shard: not here, and nobody else to ask
+        c.close()

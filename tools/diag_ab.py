@@ -5,7 +5,7 @@ import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bot7_amd  # noqa: E402
-from bot7_amd import benchmarks  # noqa: E402
+from harness import benchmarks  # noqa: E402
 settings = os.environ.get("SETTINGS", "B7_DIAG_VARIANT=0|B7_DIAG_VARIANT=1").split("|")
 ctxs = {}
 for st in settings:

@@ -4,7 +4,7 @@ import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bot7_amd  # noqa: E402
-from bot7_amd import benchmarks  # noqa: E402
+from harness import benchmarks  # noqa: E402
 c = bot7_amd.Context(0)
 d, N = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 X = c.grid_sobol(N, d, 1)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bot7_amd  # noqa: E402
-from bot7_amd import benchmarks as B  # noqa: E402
+from harness import benchmarks as B  # noqa: E402
 from oracle import cport, gp  # noqa: E402
 from conftest import make_problem  # noqa: E402
 

@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["B7_POTRF_SCHED"] = "3"
 os.environ["B7_PERSIST_STAMPS"] = "1"
 import bot7_amd  # noqa: E402
-from bot7_amd import benchmarks, _lib  # noqa: E402
+from bot7_amd import _lib
+from harness import benchmarks  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 d = 32

@@ -37,7 +37,8 @@ def run(N=2048, d=32, M=1 << 18):
     import numpy as np
     import bench
     import bot7_amd
-    from bot7_amd import _lib, benchmarks
+    from bot7_amd import _lib
+    from harness import benchmarks
     ctx = bot7_amd.Context(0)
     X_obs = bench.make_inputs(ctx, d, N, M, 0, M)
     Y = benchmarks.registry["ackley"](X_obs)

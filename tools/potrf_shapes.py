@@ -15,7 +15,7 @@ import time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bot7_amd  # noqa: E402
-from bot7_amd import benchmarks  # noqa: E402
+from harness import benchmarks  # noqa: E402
 
 shape = sys.argv[1] if len(sys.argv) > 1 else "single"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048

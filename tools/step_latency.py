@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import bot7_amd  # noqa: E402
-from bot7_amd import benchmarks  # noqa: E402
+from harness import benchmarks  # noqa: E402
 
 d, N, M, S = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (6, 256, 32768, 1)
 ctx = bot7_amd.Context(0)

@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bot7_amd
-from bot7_amd import benchmarks
+from harness import benchmarks
 c = bot7_amd.Context(0)
 d, N, M = 6, int(sys.argv[1]) if len(sys.argv) > 1 else 256, 32768
 X = c.grid_sobol(N, d, 1 + M)
