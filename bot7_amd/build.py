@@ -31,11 +31,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file flags.  covar.hip: keep the MFMA accumulators of ksx_kernel in VGPRs (the default put them in AGPRs and read every
+# result back with v_accvgpr_read: 2 of the kernel's 27 VALU instructions per output, and it is bound by VALU + MFMA issue)
+EXTRA_FLAGS = {"covar.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _compile(src):
     obj = os.path.join(BUILD, src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS + [os.path.abspath(__file__)]):
-        subprocess.check_call([HIPCC] + FLAGS + ["-c", path, "-o", obj])
+        subprocess.check_call([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj])
         return obj, True
     return obj, False
 

@@ -645,7 +645,24 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     if (aborted) {  // a hand-off timed out (the chip was shared): once more, alone
       c->persist_aborts += 1;
       B7_TRY(redo(0.0));
-      if (aborted) return b7_fail(c, B7_ERR_HIP, "gp_nll_batch: hand-off time-out (code %d) in fit %d", aborted, b);
+    }
+    if (aborted) {
+      // still no luck with the persistent schedule (the GPU is occupied by somebody else's persistent kernel): this
+      // likelihood through the launch schedule, which cannot stall -- b7_gp_fit_hyp's own fallback, jitter schedule
+      // included.  It runs in the context's fit slot, so the current fit is gone afterwards (the one case in which this
+      // call does not leave it alone; the next predict asks for a fit with B7_ERR_STATE).
+      b7_hyp h{lenscale_sq + (size_t)b * d, amp[b], noise[b], mean[b]};
+      persist_gave_up(c);
+      double nll1 = 0.0, jit1 = 0.0;
+      int info1 = 0;
+      const int rc1 = fit_hyp_core(c, &h, &nll1, &jit1, &info1, false);
+      c->fitted = false;
+      c->predicted = false;
+      B7_TRY(rc1);
+      nll_out[b] = nll1;
+      if (jitter_out) jitter_out[b] = jit1;
+      if (info_out) info_out[b] = info1;
+      continue;
     }
     if (bad != 0) {  // the jitter schedule of utils/math.lua:174-202 for this fit
       double *fro_dev = (double *)c->bterms.p + 2 * (size_t)B;

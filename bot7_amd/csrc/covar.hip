@@ -23,8 +23,14 @@
 // 4.0 TB/s (51 % of HBM peak) at d = 32; 58 % at d <= 6, 40 % at d = 39, 32 % at d = 64 (tools/ksx_rate.py).
 #include "b7_internal.h"
 #include "gemm_f64.h"
+#include "exp_table.h"
+#ifndef B7_KSX_ABLATE
+#define B7_KSX_ABLATE 0
+#endif
 
 namespace {
+
+__constant__ double exp2_tab_dev[128];  // B7_EXP2_TAB, uploaded once per process (ensure_exp_table)
 
 // ---- observation pre-scaling: zsc = z .* w (padded), zsh = (sum z^2 w)/2 ---------------------------------------
 // One wave per 64 observations: the rows are loaded and stored through an LDS tile (coalesced both ways; a thread
@@ -64,7 +70,7 @@ __global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__
     tile[lane * tld + k] = z * wk;
     s += (z * z) * wk;  // Z_ss = (Z.^2) * inv_ls, :79
   }
-  if (row0 + lane < Npad) zsh[row0 + lane] = (lane < nrows) ? 0.5 * s : __builtin_inf();
+  if (row0 + lane < Npad) zsh[row0 + lane] = (lane < nrows) ? 0.5 * s : 1e300;  // padding: covariance exactly 0 (amp_exp_nonpos)
   __syncthreads();
   double *dst = zsc + (int64_t)row0 * dpad;
 #pragma unroll 8
@@ -74,35 +80,96 @@ __global__ void __launch_bounds__(64) prep_obs_kernel(const double *__restrict__
   }
 }
 
-// exp(x) for x <= 0 (or NaN): k = rint(x log2 e), r = x - k ln2 in two pieces, Taylor to r^13 (|r| <= ln2/2:
-// truncation 4e-18), scale by 2^k with v_ldexp (gradual underflow for k < -1022).  No special-case branches.
-__device__ __forceinline__ double exp_nonpos(double x) {
-  x = (x < -1000.0) ? -1000.0 : x;  // -inf (padding) and anything that underflows anyway; NaN passes
-  const double kf = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;                      // 1/13!
-  p = __builtin_fma(p, r, 2.08767569878681e-09);          // 1/12!
-  p = __builtin_fma(p, r, 2.505210838544172e-08);         // 1/11!
-  p = __builtin_fma(p, r, 2.755731922398589e-07);         // 1/10!
-  p = __builtin_fma(p, r, 2.7557319223985893e-06);        // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873e-05);          // 1/8!
-  p = __builtin_fma(p, r, 1.984126984126984e-04);         // 1/7!
-  p = __builtin_fma(p, r, 1.388888888888889e-03);         // 1/6!
-  p = __builtin_fma(p, r, 8.333333333333333e-03);         // 1/5!
-  p = __builtin_fma(p, r, 4.1666666666666664e-02);        // 1/4!
-  p = __builtin_fma(p, r, 1.6666666666666666e-01);        // 1/3!
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)kf);
+// amp * exp(min(arg, 0)) with NaN passing (utils/math.lua:106's clamp of the distance at 0 is TH's: it compares, it does not
+// sanitise), in 16 VALU instructions (the Taylor-13 form it replaces took 27: 36 -> 27 per output of the kernel, which is
+// bound by VALU + MFMA issue on the one fp64 pipe):
+//   a  = max(min(arg, 0), -1000)               v_min / v_max drop a NaN; it is put back below
+//   nb = fma(a, 128/ln2, 1.5 * 2^52)           the low mantissa bits of nb ARE n = rint(a * 128/ln2) (two's complement)
+//   r  = a - n * ln2/128 in two pieces         HEAD has 35 bits, so n * HEAD is exact for |n| < 2^18; |r| <= ln2/256
+//   q  = r * (1 + r/2 + r^2/6 + r^3/24 + r^4/120)        e^r - 1, truncation r^6/720 <= 5.5e-19
+//   q  = fma(arg, 0.0, q)                      NaN (or inf) in arg -> NaN; otherwise adds a signed zero
+//   amp * exp(a) = 2^(n >> 7) * T[n & 127] * (1 + q),  T[j] = amp * 2^(j/128) in LDS, v_ldexp for the power of two
+// (gradual underflow; a = -1000 gives exactly 0).  Measured against long-double exp over 2e7 arguments in [-40, 0]:
+// relative error <= 1.85 * 2^-53 with amp = 1 (tools/gen_exp_table.py writes the table and the constants).
+// Padding observations carry zs/2 = 1e300 (not +inf: inf * 0 would make the NaN carrier fire): arg = -1e300 -> exactly 0.
+// Four arguments at a time, stage by stage: one such chain is 14 dependent fp64 instructions (8.6 cycles each when the next
+// one waits for it, 4.8 when it does not), and the compiler, left to itself, ran the four chains of a 16x16 tile nearly one
+// after the other -- the epilogue was bound by latency, not by issue (tools/ksx_ablate.py: a third fewer instructions
+// changed nothing).  Written as stages over r = 0..3 the four chains interleave and each instruction's latency is covered
+// by the other three.
+// keeps the instruction scheduler from moving anything across: without it the four Horner chains are emitted one after the
+// other again (it minimises live registers; there are plenty here)
+#define B7_STAGE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void amp_exp_nonpos4(const double (&arg)[4], const double *__restrict__ tab, double (&out)[4]) {
+  double a[4], nb[4], nf[4], r[4], p[4], q[4], t[4];
+  int n[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = __builtin_fmin(arg[i], 0.0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = __builtin_fmax(a[i], -1000.0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nb[i] = __builtin_fma(a[i], B7_EXP_INV, B7_EXP_MAGIC);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    n[i] = __double2loint(nb[i]);
+#if B7_KSX_ABLATE & 2    // every lane reads the same table entry: no LDS bank conflicts
+    t[i] = tab[(n[i] >> 20) & 1];
+#else
+    t[i] = tab[n[i] & 127];
+#endif
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nf[i] = nb[i] - B7_EXP_MAGIC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fma(nf[i], -B7_EXP_HEAD, a[i]);
+B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fma(nf[i], -B7_EXP_TAIL, r[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(r[i], 1.0 / 120.0, 1.0 / 24.0);
+B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(p[i], r[i], 1.0 / 6.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(p[i], r[i], 0.5);
+B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(p[i], r[i], 1.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = r[i] * p[i];
+B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = __builtin_fma(arg[i], 0.0, q[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = __builtin_ldexp(__builtin_fma(t[i], q[i], t[i]), n[i] >> 7);
 }
 
-__device__ __forceinline__ double pair_swap(double v) {  // value held by lane ^ 1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
+// out[0] = even lane ? a : (lane ^ 1)'s b;  out[1] = odd lane ? b : (lane ^ 1)'s a.  Select and lane exchange are ONE
+// instruction per 32-bit half, v_cndmask_b32_dpp (VOP2: D = VCC ? src1 : dpp(src0)), which hipcc does not form from
+// update_dpp + a select (it emitted v_mov_b32_dpp + 3 v_cndmask per half: 20 VALU instructions per 16x16 tile against
+// 8 here, and the kernel is bound by VALU + MFMA issue).  The two s_mov between the producers of a / b and the first DPP
+// read are the 2 wait states that hazard needs (VALU writes VGPR -> DPP reads it); VCC is rewritten, hence the clobber.
+__device__ __forceinline__ void pair_pack(double a, double b, d2_t &out) {
+  const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  int o0l, o0h, o1l, o1h;
+  asm volatile(
+      "s_mov_b32 vcc_lo, 0x55555555\n\t"
+      "s_mov_b32 vcc_hi, 0x55555555\n\t"
+      "s_nop 0\n\t"
+      "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_not_b64 vcc, vcc\n\t"
+      "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(o0l), "=&v"(o0h), "=&v"(o1l), "=&v"(o1h)
+      : "v"(alo), "v"(ahi), "v"(blo), "v"(bhi)
+      : "vcc", "scc");
+  out[0] = __hiloint2double(o0h, o0l);
+  out[1] = __hiloint2double(o1h, o1l);
 }
 
 // ---- K(X*,X) chunk / K(X,X) -----------------------------------------------------------------------------------
@@ -148,6 +215,7 @@ __global__ void __launch_bounds__(256)
   double *sh = so + 2 * KO * stride;        // 2 x KO   zs/2 of the slab
   double *sal = sh + 2 * KO;                // 2 x KO   alpha of the slab
   double *shq = sal + 2 * KO;               // KQ       xs/2 of the queries
+  double *stab = shq + KQ;                  // 128      amp * 2^(j/128)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int64_t qbase = row0 + (int64_t)blockIdx.x * KQ;
@@ -155,6 +223,7 @@ __global__ void __launch_bounds__(256)
   const int qrow = tid >> 2, qq4 = tid & 3;     // query staging: 64 rows, 4 threads per row
   constexpr int half = DPAD >> 1;            // 16-byte chunks per row
 
+  if (tid < 128) stab[tid] = amp * exp2_tab_dev[tid];
   // query tile (zero-padded columns)
   {
     int64_t g = qbase + qrow;
@@ -232,31 +301,50 @@ __global__ void __launch_bounds__(256)
         double bf[KSTEPS];
 #pragma unroll
         for (int k4 = 0; k4 < KSTEPS; ++k4) bf[k4] = ob[4 * k4];
+#if B7_KSX_ABLATE & 8   // one MFMA per tile instead of DPAD / 4
+        c = mfma_f64(qf[0], bf[0], c);
+#else
 #pragma unroll
         for (int k4 = 0; k4 < KSTEPS; ++k4) c = mfma_f64(qf[k4], bf[k4], c);
+#endif
       }
       const double hk = sh[cur * KO + t * 16 + lr];
       const double al = sal[cur * KO + t * 16 + lr];
-      double kv[4];
+      double kv[4], arg[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double arg = (c[r] - hq[r]) - hk;  // = -1/2 * (((-2 c) + xs) + zs), utils/math.lua:82
-        arg = (arg > 0.0) ? 0.0 : arg;     // :106 clamp(0, huge) on the distance; NaN passes
-        kv[r] = amp * exp_nonpos(arg);
-        macc[r] = __builtin_fma(kv[r], al, macc[r]);
-      }
+      for (int r = 0; r < 4; ++r) arg[r] = (c[r] - hq[r]) - hk;  // = -1/2 * (((-2 c) + xs) + zs), utils/math.lua:82
+#if B7_KSX_ABLATE & 4   // diagnostic builds only (tools/ksx_ablate.py): no exp
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kv[r] = arg[r];
+#else
+      amp_exp_nonpos4(arg, stab, kv);  // :106 clamp(0, huge) on the distance (NaN passes), amp * exp(-D/2)
+#endif
+#pragma unroll
+      for (int r = 0; r < 4; ++r) macc[r] = __builtin_fma(kv[r], al, macc[r]);
+      // rows (lq, lq+4, lq+8, lq+12) x column lr  ->  16-byte stores of two adjacent columns: even lanes write rows r = 0
+      // and 2 (their own value, then the odd neighbour's), odd lanes rows r = 1 and 3 (the even neighbour's, then their own)
+      d2_t v01, v23;
+      pair_pack(kv[0], kv[1], v01);
+      pair_pack(kv[2], kv[3], v23);
       {
-        // rows (lq, lq+4, lq+8, lq+12) x column lr  ->  16-byte stores of two adjacent columns
-        const double s01 = pair_swap(odd ? kv[0] : kv[1]);
-        const double s23 = pair_swap(odd ? kv[2] : kv[3]);
-        d2_t v01, v23;
-        v01[0] = odd ? s01 : kv[0];
-        v01[1] = odd ? kv[1] : s01;
-        v23[0] = odd ? s23 : kv[2];
-        v23[1] = odd ? kv[3] : s23;
         double *p = orow + o0 + t * 16;
+#if B7_KSX_ABLATE & 1   // no stores (a condition that never holds keeps the values alive)
+        if (v01[0] == 1.2345e-300) {
+#endif
+#if B7_KSX_ABLATE & 16  // the same bytes to row-contiguous addresses (2 rows x 512 B per instruction; wrong placement)
+        double *pi = out + ((int64_t)blockIdx.x * KQ + wave * 16 + 4 * t + (lane >> 5)) * Npad + o0 + (lane & 31) * 2;
+        *reinterpret_cast<d2_t *>(pi) = v01;
+        *reinterpret_cast<d2_t *>(pi + (int64_t)2 * Npad) = v23;
+#elif B7_KSX_ABLATE & 32  // non-temporal stores
+        __builtin_nontemporal_store(v01, reinterpret_cast<d2_t *>(p));
+        __builtin_nontemporal_store(v23, reinterpret_cast<d2_t *>(p + (int64_t)8 * Npad));
+#else
         *reinterpret_cast<d2_t *>(p) = v01;
         *reinterpret_cast<d2_t *>(p + (int64_t)8 * Npad) = v23;
+#endif
+#if B7_KSX_ABLATE & 1
+        }
+#endif
       }
     }
     if (more) store_slab(cur ^ 1);
@@ -296,7 +384,16 @@ __global__ void __launch_bounds__(256)
 
 size_t ksx_lds_bytes(int dpad) {
   const int KO = ksx_slab(dpad);
-  return sizeof(double) * ((size_t)(KQ + 2 * KO) * (dpad + 1) + 4 * KO + KQ);
+  return sizeof(double) * ((size_t)(KQ + 2 * KO) * (dpad + 1) + 4 * KO + KQ + 128);
+}
+
+// the 2^(j/128) table goes to constant memory once per process and device
+int ensure_exp_table(b7_ctx *c) {
+  static bool done[64] = {false};
+  if (c->device < 64 && done[c->device]) return B7_OK;
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_dev), B7_EXP2_TAB, sizeof(B7_EXP2_TAB)));
+  if (c->device < 64) done[c->device] = true;
+  return B7_OK;
 }
 
 template <int DPAD>
@@ -304,6 +401,7 @@ int ksx_launch(b7_ctx *c, dim3 grid, const double *xq, int64_t row0, int64_t Mto
                const double *alpha, double meanc, double *out, double *mu) {
   const size_t lds = ksx_lds_bytes(DPAD);
   auto kern = ksx_kernel<DPAD>;
+  B7_TRY(ensure_exp_table(c));
   // dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per workgroup)
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));

@@ -172,7 +172,7 @@ class gp_regressor(abstract):
         import threading
         C, d = len(self._chain_thetas), X.shape[1]
         lo, hi = self._bounds(X, Y)
-        key = (X.shape, Y.shape, float(X.sum()), float(Y.sum()))
+        key = self._data_key(X, Y)
         if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
             self.ctx.gp_set_data(X, Y)
             self._resident_key = (key, self.ctx.fit_token)
@@ -277,12 +277,22 @@ class gp_regressor(abstract):
         return isinstance(X1, DeviceGrid) and X1.ctx is self.ctx and X1.shape[0] == self.ctx.grid_shape()[0] \
             and getattr(X1, "version", -1) == self.ctx.grid_version
 
+    @staticmethod
+    def _data_key(X, Y):
+        """What identifies the resident observations: their CONTENT (shapes and sums collide: Y and -Y with zero sum, two
+        responses swapped between rows).  N x (d + c) doubles through blake2b is nothing next to a fit."""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        h.update(np.ascontiguousarray(X).tobytes())
+        h.update(np.ascontiguousarray(Y).tobytes())
+        return (X.shape, Y.shape, h.digest())
+
     def stage(self, X_obs, Y_obs, X_hid):
         """Make (X_obs, Y_obs) the resident data and X_hid the resident grid of the context, uploading only what
         is not there already (for b7_eval_nominate, which refits the resident data under S hyper samples)."""
         X = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
         Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
-        key = (X.shape, Y.shape, float(X.sum()), float(Y.sum()))
+        key = self._data_key(X, Y)
         if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
             self.ctx.gp_set_data(X, Y)
             self._resident_key = (key, self.ctx.fit_token)

@@ -149,7 +149,9 @@ int b7_gp_predict_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *mean_host, double 
  * lenscale_sq is B x d row-major; amp / noise / mean have B entries; nll_out[B] as b7_gp_fit_hyp's (same jitter schedule
  * per fit: jitter_out[B] / info_out[B], nullable).  The B factorisations run concurrently in ONE persistent launch (each
  * a chain of workgroups; 28 fit on the chip at N <= 256, 7 at N <= 512, larger ones go one after the other), with L z = r
- * solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched.
+ * solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched -- except
+ * when a fit's hand-offs time out twice (the GPU is shared with another persistent kernel): that likelihood is then
+ * evaluated through the launch schedule in the context's fit slot, and the next predict asks for a new fit (B7_ERR_STATE).
  * One response column, N <= 4096. */
 int b7_gp_nll_batch(b7_ctx *ctx, int B, const double *lenscale_sq, const double *amp, const double *noise,
                     const double *mean, double *nll_out, double *jitter_out, int *info_out);

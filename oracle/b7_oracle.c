@@ -216,7 +216,8 @@ int orc_i4_sobol(orc_sobol *g, int dims, double *seed_io, double *quasi) {
   return 0;
 }
 
-/* grids/sobol.lua:58-90 generate (both mins and maxes given, or neither).  out is size x dims. */
+/* grids/sobol.lua:58-90 generate with both mins and maxes, or neither (the one-sided maps: orc_affine on the result).
+ * out is size x dims. */
 int orc_sobol_generate(int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
                        double *out) {
   if (!(dims >= 1 && dims < ORC_MAX_DIMS)) return -2; /* :36 assert(dims < max_dims) */
@@ -252,14 +253,35 @@ int orc_sobol_bank(int dims, double *bank_out /* dims x 30 */) {
   return 0;
 }
 
-/* grids/random.lua:27-33 affine map of a given uniform sample (the RNG stream itself is Torch's). */
+/* grids/sobol.lua:79-85 = grids/random.lua:27-33: the map applied to a generated grid (the RNG stream of grids/random.lua
+ * is Torch's).  Both given: cmul by (maxes + -mins), then add mins.  mins only (:82-83): grid:add(torch.add(mins,
+ * grid:min(1)[1])) -- the column minimum is ADDED to mins, as the reference writes it.  maxes only (:84-85):
+ * grid:cmul(torch.cdiv(maxes, grid:max(1)[1])).  One rounded operation per column for the shift / scale, one per element. */
 void orc_affine(double *grid, int64_t size, int dims, const double *mins, const double *maxes) {
-  for (int64_t j = 0; j < size; ++j)
+  if (mins && maxes) {
+    for (int64_t j = 0; j < size; ++j)
+      for (int i = 0; i < dims; ++i) {
+        double w = maxes[i] + (-mins[i]);
+        double v = grid[j * dims + i] * w;
+        grid[j * dims + i] = v + mins[i];
+      }
+  } else if (mins && size > 0) {
     for (int i = 0; i < dims; ++i) {
-      double w = maxes[i] + (-mins[i]);
-      double v = grid[j * dims + i] * w;
-      grid[j * dims + i] = v + mins[i];
+      double lo = grid[i];
+      for (int64_t j = 1; j < size; ++j)
+        if (grid[j * dims + i] < lo) lo = grid[j * dims + i];
+      double shift = mins[i] + lo;
+      for (int64_t j = 0; j < size; ++j) grid[j * dims + i] = grid[j * dims + i] + shift;
     }
+  } else if (maxes && size > 0) {
+    for (int i = 0; i < dims; ++i) {
+      double hi = grid[i];
+      for (int64_t j = 1; j < size; ++j)
+        if (grid[j * dims + i] > hi) hi = grid[j * dims + i];
+      double scale = maxes[i] / hi;
+      for (int64_t j = 0; j < size; ++j) grid[j * dims + i] = grid[j * dims + i] * scale;
+    }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ def lib():
         L.orc_i4_bit_lo0.argtypes = [C.c_double]
         L.orc_sobol_generate.argtypes = [C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, _dp]
         L.orc_sobol_bank.argtypes = [C.c_int, _dp]
-        L.orc_affine.argtypes = [_dp, C.c_int64, C.c_int, _dp, _dp]
+        L.orc_affine.argtypes = [_dp, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         for f in (L.orc_erf, L.orc_norm_cdf, L.orc_norm_pdf):
             f.restype = C.c_double
             f.argtypes = [C.c_double]
@@ -62,6 +62,8 @@ def sobol(size, dims, skip=1, mins=None, maxes=None):
                                   None if mx is None else mx.ctypes.data, out)
     if rc != 0:
         raise ValueError("orc_sobol_generate failed rc=%d" % rc)
+    if (mins is None) != (maxes is None):        # grids/sobol.lua:82-85: one of the two alone
+        out = affine(out, mins, maxes)
     return out
 
 
@@ -72,9 +74,12 @@ def sobol_bank(dims):
     return out
 
 
-def affine(grid, mins, maxes):
+def affine(grid, mins=None, maxes=None):
+    """grids/sobol.lua:79-85 / grids/random.lua:27-33 on a copy of grid: both, mins only, maxes only, or neither."""
     g = _f64(grid).copy()
-    lib().orc_affine(g, g.shape[0], g.shape[1], _f64(mins).ravel(), _f64(maxes).ravel())
+    mn = None if mins is None else _f64(mins).ravel()
+    mx = None if maxes is None else _f64(maxes).ravel()
+    lib().orc_affine(g, g.shape[0], g.shape[1], None if mn is None else mn.ctypes.data, None if mx is None else mx.ctypes.data)
     return g
 
 

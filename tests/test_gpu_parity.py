@@ -1798,3 +1798,52 @@ def test_lockstep_chains_follow_the_single_chain_sampler_and_batch_their_densiti
     t_seq = time.perf_counter() - t0
     print("8 chains, one update each: lock-step %.2f ms (%d likelihoods in %d batches); chain by chain incl. burn-in replay %.2f ms"
           % (t_lock * 1e3, evals, batches, t_seq * 1e3))
+
+
+# ---- ADVICE r2 ---------------------------------------------------------------------------------------------------------
+def test_eval_nominate_leaves_no_half_described_fit_behind(ctx, orc):
+    """After b7_eval_nominate the context's fit slot holds none of the samples (include/bot7hip.h): with one sample the fit's
+    lengthscales sat in the batch staging block, and b7_gp_append / b7_gp_fantasize would have rescaled the observations with
+    whatever an earlier fit left in the slot's own place.  Both must be refused until the caller fits again, and a fit +
+    append afterwards equals the full refit."""
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, 50, 700, B.hartmann6)
+    ctx.grid_upload(X_hid)
+    ctx.gp_fit(X_obs, Y, hyp["lenscale_sq"] * 3.0, hyp["amp"], hyp["noise"], hyp["mean"])   # other lengthscales in the slot
+    ctx.gp_set_data(X_obs, Y)
+    for S in (1, 2):
+        ctx.eval_nominate([dict(hyp, lenscale_sq=hyp["lenscale_sq"] * (1 + 0.1 * s)) for s in range(S)], score="ei", fmin=[float(Y.min())])
+        with pytest.raises(bot7_amd.Bot7HipError) as e:
+            ctx.gp_append(X_hid[0], B.hartmann6(X_hid[:1])[0])
+        assert e.value.code == -4
+        with pytest.raises(bot7_amd.Bot7HipError) as e:
+            ctx.gp_fantasize(X_hid[:3], 4)
+        assert e.value.code == -4
+    ctx.gp_fit_hyp(**hyp)
+    ctx.gp_append(X_hid[0], B.hartmann6(X_hid[:1])[0])
+    L1, a1, _ = ctx.gp_download(51)
+    ctx.gp_fit(np.concatenate([X_obs, X_hid[:1]]), np.concatenate([Y, B.hartmann6(X_hid[:1])]), **hyp)
+    L2, a2, _ = ctx.gp_download(51)
+    assert np.allclose(L1, L2, rtol=1e-9, atol=1e-12) and np.allclose(a1, a2, rtol=1e-6, atol=1e-9)
+
+
+def test_stage_keys_on_the_content_of_the_observations(ctx, orc):
+    """models.gp_regressor.stage decides whether the resident data are current: shapes and sums are not enough (Y and -Y
+    with zero sum; two responses swapped).  The nomination after such a change must be the oracle's for the NEW data."""
+    import bot7_amd
+    rng = np.random.default_rng(8)
+    X_obs, X_hid = rng.random((40, 3)), rng.random((900, 3))
+    Y = rng.normal(size=(40, 1))
+    Y -= Y.mean()
+    Y[0, 0] -= Y.sum()                                # exactly zero sum for Y and -Y alike? make it so to the last bit
+    model = bot7_amd.models.gp_regressor({}, context=ctx)
+    grid = bot7_amd.grids.DeviceGrid(X_hid, ctx, -1)
+    hyp = {"lenscale_sq": np.full(3, 0.4), "amp": 1.0, "noise": 1e-3, "mean": 0.0}
+    Ys = Y.copy()
+    Ys[[3, 7]] = Ys[[7, 3]]                           # same shape, same sum, different data
+    for Yk in (Y, -Y, Ys):
+        model.stage(X_obs, Yk, grid)
+        v, i = ctx.eval_nominate([hyp], score="ei", fmin=[float(Yk.min())])
+        mu, var = orc.gp.predict(orc.gp.fit(X_obs, Yk, **hyp), X_hid)
+        wi, wv = orc.c.argmax_first(orc.c.ei(mu, var, [float(Yk.min())]))
+        assert i == wi, "stale observations were scored"

@@ -270,3 +270,53 @@ def test_nominate_commit_on_a_plain_context_and_a_world_of_one(ctx, orc):
             with pytest.raises(bot7_amd.Bot7HipError):
                 c.nominate_commit(off, off)                     # the row before this shard: not here, and nobody else to ask
         c.close()
+
+
+# ---- one-sided affine maps of the grid generators (grids/sobol.lua:82-85, grids/random.lua:29-32) ----------------------
+def test_oracle_one_sided_maps_follow_the_lua_lines(orc):
+    """mins only: grid:add(torch.add(mins, grid:min(1)[1])); maxes only: grid:cmul(torch.cdiv(maxes, grid:max(1)[1])) --
+    restated here with numpy straight from those two lines (one rounding for the per-column term, one per element)."""
+    g = orc.c.sobol(257, 5, 3)
+    mins, maxes = np.array([-1.0, 0.5, 2.0, 0.0, 1e-3]), np.array([2.0, 3.0, 0.25, 1.0, 7.0])
+    assert np.array_equal(orc.c.sobol(257, 5, 3, mins=mins), g + (mins + g.min(axis=0)))
+    assert np.array_equal(orc.c.sobol(257, 5, 3, maxes=maxes), g * (maxes / g.max(axis=0)))
+    assert np.array_equal(orc.c.sobol(257, 5, 3, mins=mins, maxes=maxes), g * (maxes + (-mins)) + mins)
+    assert np.array_equal(orc.c.affine(g), g)
+
+
+@pytest.mark.gpu
+def test_one_sided_grid_maps_match_the_oracle_on_a_context_and_on_a_group(ctx, orc):
+    import bot7_amd
+    rng = np.random.default_rng(5)
+    for dims, size, skip in ((2, 300, 1), (7, 4097, 5), (39, 1000, 2)):
+        mins, maxes = rng.normal(size=dims), rng.random(dims) + 0.5
+        for kw in ({"mins": mins}, {"maxes": maxes}):
+            want = orc.c.sobol(size, dims, skip, **kw)
+            assert np.array_equal(ctx.grid_sobol(size, dims, skip, **kw), want), (dims, list(kw))
+            assert np.array_equal(ctx.grid_download(), want)
+            raw = ctx.grid_random(size, dims, seed=9)
+            assert np.array_equal(ctx.grid_random(size, dims, seed=9, **kw), orc.c.affine(raw, **kw))
+            lo, hi = ctx.grid_colrange()
+            got = ctx.grid_download()
+            assert np.array_equal(lo, got.min(axis=0)) and np.array_equal(hi, got.max(axis=0))
+            for n in (2, 3):
+                g = bot7_amd.Group([0] * n)     # the column extremes are those of the UNION of the members' shards
+                g.grid_sobol(size, dims, skip, **kw)
+                assert np.array_equal(g.grid_download(), want), (dims, list(kw), n)
+                g.grid_random(size, dims, seed=9, **kw)
+                assert np.array_equal(g.grid_download(), orc.c.affine(raw, **kw))
+                g.close()
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r2: the dlopen failure path called dlerror() twice and built a std::string from NULL.  In a fresh process with
+    the library name forced to miss, b7_comm_unique_id must come back with B7_ERR_COMM and a message."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from bot7_amd import _lib\n"
+            "try:\n    _lib.comm_unique_id()\n    print('no error')\n"
+            "except _lib.Bot7HipError as e:\n    print('code', e.code, str(e))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, B7_RCCL_LIB="/nonexistent/librccl-not-here.so"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "code -7" in out.stdout and "librccl-not-here" in out.stdout, out.stdout
