@@ -236,6 +236,12 @@ def main():
 
     def step(samples):
         if obj_name == "dngo":
+            if ctx.comm_info()[1] == world:
+                # bots/bayesopt.lua:65-66 + :96 over models/dngo.lua:155-175 as ONE call: features of the observations,
+                # the Bayesian linear head, features of every candidate (recomputed each step, as the reference does),
+                # mean / variance, EI, the (global) arg-max
+                return ctx.blr_eval_nominate(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean, score="ei", fmin=fmin,
+                                             global_row_offset=shard.lo)
             ctx.blr_fit_x(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean)
             ctx.blr_basis(Wn, bn, "Tanh")
             ctx.blr_predict(download=False)
@@ -367,7 +373,8 @@ def main():
         "ksx_hbm_gbs": ksx_gbs, "ksx_hbm_frac": (ksx_gbs / HBM_PEAK_GBS) if ksx_gbs else None,
         "phases": phases,
         "best": {"value": best[0], "index1": best[1]},
-        "step_api": "b7_blr_* + b7_score_* + b7_score_finish_global" if obj_name == "dngo" else
+        "step_api": ("b7_blr_eval_nominate (one call, one host synchronisation per step)" if ctx.comm_info()[1] == world
+                     else "b7_blr_* + b7_score_* per step, gloo exchange") if obj_name == "dngo" else
                     ("b7_eval_nominate (one call, one host synchronisation per step)" if ctx.comm_info()[1] == world
                      else "b7_gp_predict_hyp + b7_score_* per sample, gloo exchange"),
     }

@@ -1315,11 +1315,19 @@ static int upload_net(b7_ctx *c, const b7_mlp *net, int *z_out) {
   return B7_OK;
 }
 
+// The feature matrix: round_up(M, 256) rows x zpad columns, of which the basis kernels write the first z of the first M
+// rows.  Everything else must be zero (the variance GEMM reads whole padded rows) and is zeroed when the buffer is
+// (re)allocated or its column layout changes -- not on every call: a 67 MB memset per nomination was a sixth of a cfg5 step.
 static int feat_alloc(b7_ctx *c, int64_t M, int z) {
   const int zpad = (int)round_up(z, B7_NPAD);
   const size_t bytes = sizeof(double) * (size_t)round_up(M, B7_MROWS) * zpad;
+  const bool grown = c->feat.cap < bytes;
   B7_TRY(b7_ensure(c, c->feat, bytes));
-  B7_HIP(c, hipMemsetAsync(c->feat.p, 0, bytes, c->stream));
+  if (grown || c->feat_z != z || c->feat_zeroed_bytes < bytes) {
+    B7_HIP(c, hipMemsetAsync(c->feat.p, 0, c->feat.cap, c->stream));
+    c->feat_zeroed_bytes = c->feat.cap;
+    c->feat_z = z;
+  }
   c->Mfeat = M;
   c->zdim = z;
   c->predicted = false;
@@ -1495,6 +1503,157 @@ int b7_blr_predict(b7_ctx *c, double *mean_host, double *var_host) {
   if (var_host) B7_HIP(c, hipMemcpyAsync(var_host, c->var.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
   if (mean_host || var_host) B7_HIP(c, hipStreamSynchronize(c->stream));
   return B7_OK;
+}
+
+// ---- models/dngo.lua:155-175 + bots/bayesopt.lua:65-66 + :96 as ONE call ----------------------------------------------
+// The DNGO branch of bayesopt:eval scores once (no hyper marginalisation): features of the observations, the Bayesian
+// linear head, features of every candidate, predictive mean / variance, the acquisition, score:max(1).  Through the
+// separate entry points that is six calls and four host synchronisations around 0.2 ms of GPU work; here everything is
+// enqueued back to back (the head's Cholesky reports its pivot status into pinned memory in stream order), the arg-max
+// record follows, and the host waits once.  A failed pivot (rare: K = beta Z'Z + alpha I is positive definite by
+// construction) redoes the fit through b7_blr_fit_x's jitter schedule and scores again.
+static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, int z, double alpha_prec,
+                           double beta, double mean, std::vector<double> &rb) {
+  const int d = net->dims[0], zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * ((size_t)N * d + (size_t)N * z)));
+  B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
+  B7_TRY(b7_ensure(c, c->K, nn));
+  B7_TRY(b7_ensure(c, c->L, nn));
+  B7_TRY(b7_ensure(c, c->Linv, nn));
+  B7_TRY(b7_ensure(c, c->W, nn));
+  B7_TRY(b7_ensure(c, c->dinv, sizeof(double) * (np + B7_PANEL) * B7_PANEL));
+  B7_TRY(b7_ensure(c, c->alpha, sizeof(double) * np));
+  B7_TRY(b7_ensure(c, c->resid, sizeof(double) * np));
+  B7_TRY(b7_ensure(c, c->tmpvar, sizeof(double) * (size_t)nk));
+  B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
+  c->have_data = false;
+  c->fitted = false;
+  c->predicted = false;
+  c->N = z;
+  c->Npad = zpad;
+  c->ycols = 1;
+  c->yld = 1;
+  c->mean = mean;
+  c->noise = 1.0 / beta;
+  c->amp = 0.0;
+  c->model_kind = 1;
+  double *xdev = (double *)c->tmpmu.p, *zdev = xdev + (size_t)N * d;
+  B7_HIP(c, hipMemcpyAsync(xdev, X0, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_mlp_forward(c, xdev, N, d, (const double *)c->netbuf.p, net->dims, net->n_layers, net->activation, zdev, z));
+  B7_TRY(launch_transpose_pad(c, zdev, N, z, z, (double *)c->tmpgrid.p, zpad, nk));
+  rb.assign((size_t)nk, 0.0);
+  for (int i = 0; i < N; ++i) rb[i] = beta * (Y0[i] - mean);
+  B7_HIP(c, hipMemcpyAsync(c->tmpvar.p, rb.data(), sizeof(double) * nk, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_gemm_nt(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpgrid.p, nk, (double *)c->W.p, zpad, zpad,
+                        zpad, nk));
+  B7_TRY(launch_blr_assemble(c, (const double *)c->W.p, (double *)c->K.p, z, zpad, alpha_prec, beta));
+  B7_TRY(launch_gemv_rows(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpvar.p, nk, 0.0, 0, zpad, zpad,
+                          (double *)c->resid.p));
+  B7_TRY(launch_potrf(c, 0.0, true));
+  if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
+  B7_TRY(launch_alpha(c));
+  // the pivot report of the plain attempt, into the pinned fit-report block in stream order
+  B7_HIP(c, hipMemcpyAsync(c->pinned, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
+  c->fitted = true;
+  return B7_OK;
+}
+
+// features of the resident grid (recomputed, as models/dngo.lua:155-171 does on every predict), mean, variance, score
+static int blr_enqueue_score(b7_ctx *c, const b7_mlp *net, int z, const b7_score_spec *spec) {
+  const int zpad = (int)round_up(z, B7_NPAD);
+  B7_TRY(feat_alloc(c, c->M, z));
+  B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M));
+  B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
+  B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
+  bool mean_done = false;
+  B7_TRY(launch_mlp_forward_mean(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p, net->dims,
+                                 net->n_layers, net->activation, (double *)c->feat.p, zpad, (const double *)c->alpha.p, c->mean,
+                                 (double *)c->mu.p, &mean_done));
+  if (!mean_done)
+    B7_TRY(launch_gemv_rows(c, (const double *)c->feat.p, c->Npad, (const double *)c->alpha.p, c->Npad, c->mean, 0, c->M, c->M,
+                            (double *)c->mu.p));
+  B7_TRY(launch_post(c, (const double *)c->feat.p, 0, round_up(c->M, B7_MROWS), c->M, (double *)c->var.p));
+  c->predicted = true;
+  c->Mpred = c->M;
+  // bots/bayesopt.lua:65-66: the score of the one model, no accumulation over samples -> written, not added
+  double *fd = nullptr;
+  if (spec->kind == B7_SCORE_EI) {
+    B7_TRY(stage_fmin(c, spec->fmin, &fd));
+    B7_TRY(launch_ei(c, (const double *)c->mu.p, (const double *)c->var.p, fd, spec->tradeoff, c->M, 1, (double *)c->acc.p, false));
+  } else {
+    B7_TRY(launch_cb(c, (const double *)c->mu.p, (const double *)c->var.p, spec->tradeoff, spec->upper, spec->sign, c->M, 1,
+                     (double *)c->acc.p, false));
+  }
+  c->acc_valid = true;
+  return B7_OK;
+}
+
+int b7_blr_eval_nominate(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec,
+                         double beta, double mean, const b7_score_spec *spec, int64_t global_row_offset, double *best_val,
+                         int64_t *best_idx1, double *jitter_used) {
+  if (!c) return B7_ERR_INVALID;
+  if (c->group) return b7_fail(c, B7_ERR_STATE, "blr_eval_nominate: this context belongs to a group");
+  const bool exchange = c->comm && c->comm_world > 1;
+  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  if (jitter_used) *jitter_used = 0.0;
+  int rc = B7_OK, z = 0;
+  if (!X0 || !Y0 || N < 1 || !spec) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate: bad arguments");
+  else if (!(alpha_prec > 0.0) || !(beta > 0.0)) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate: precisions must be > 0");
+  else if (spec->kind != B7_SCORE_EI && spec->kind != B7_SCORE_CB) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate: unknown score kind %d", spec->kind);
+  else if (spec->kind == B7_SCORE_EI && !spec->fmin) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate: EI needs fmin");
+  else if (global_row_offset < 0) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate: negative row offset");
+  else if (c->M == 0 && !exchange) rc = b7_fail(c, B7_ERR_STATE, "blr_eval_nominate: no candidate grid on this context");
+  if (rc == B7_OK) rc = hipSetDevice(c->device) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "hipSetDevice failed");
+  if (rc == B7_OK) rc = upload_net(c, net, &z);
+  if (rc == B7_OK && z > 256) rc = b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
+  if (rc == B7_OK && c->M > 0 && net->dims[0] != c->d)
+    rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate: network input width %d != grid dims %d", net->dims[0], c->d);
+  std::vector<double> rb;  // beta (Y - mean): the source of an asynchronous copy, alive until the synchronisation below
+  auto local = [&]() -> int {
+    if (c->M == 0) return B7_OK;   // an empty shard: nothing to score, but the exchange is collective
+    B7_TRY(blr_enqueue_fit(c, net, X0, Y0, N, z, alpha_prec, beta, mean, rb));
+    return blr_enqueue_score(c, net, z, spec);
+  };
+  auto redo = [&]() -> int {        // the jitter schedule of utils/math.lua:159-218, through the synchronous fit
+    B7_TRY(b7_blr_fit_x(c, net, X0, Y0, N, alpha_prec, beta, mean, nullptr));
+    if (jitter_used) *jitter_used = -2.0;  // "a jitter was needed" (its size is the fit's business; see b7_blr_fit_x)
+    return blr_enqueue_score(c, net, z, spec);
+  };
+  const int *report = static_cast<const int *>(c->pinned);
+  if (!exchange) {
+    B7_TRY(rc);
+    B7_TRY(local());
+    B7_TRY(exch_local(c, 1.0, global_row_offset, rank, world, true));
+    B7_TRY(exch_fetch(c, 0, world));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (report[0] != 0 || report[1] != 0) {
+      if (report[1] != 0) persist_gave_up(c);
+      B7_TRY(redo());
+      B7_TRY(exch_local(c, 1.0, global_row_offset, rank, world, true));
+      B7_TRY(exch_fetch(c, 0, world));
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
+  }
+  if (rc == B7_OK) rc = local();
+  if (rc == B7_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "blr_eval_nominate: stream failed");
+  if (rc == B7_OK && c->M > 0 && (report[0] != 0 || report[1] != 0)) {
+    if (report[1] != 0) persist_gave_up(c);
+    rc = redo();
+  }
+  if (rc == B7_OK) rc = exch_local(c, 1.0, global_row_offset, rank, world, true);
+  const std::string own = c->err;
+  if (rc != B7_OK) B7_TRY(exch_fail_record(c, rank, world, rc));
+  B7_TRY(exch_allreduce(c));
+  B7_TRY(exch_fetch(c, 0, world));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (rc != B7_OK) {
+    exch_forget(c);
+    c->err = own;
+    return rc;
+  }
+  return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
 }
 
 // ---- scores --------------------------------------------------------------------------------------------

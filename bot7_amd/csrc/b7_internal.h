@@ -135,6 +135,8 @@ struct b7_ctx {
   DevBuf tmpmu, tmpvar;
   DevBuf fant;   // fantasize workspace (pending-point covariance pieces)
   DevBuf feat;   // DNGO basis features of the resident grid: Mfeat x Npad (zero-padded columns)
+  size_t feat_zeroed_bytes = 0;  // how much of `feat` was zeroed when it was laid out for feat_z columns
+  int feat_z = -1;
   int64_t Mfeat = 0;
   int zdim = 0;
   uint64_t feat_version = 0, grid_version = 0;
@@ -277,6 +279,9 @@ int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, co
 int launch_append_vectors(b7_ctx *c, const double *krow, double *lvec, double *uvec, double *part, double *evec);
 int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
                        int n_layers, int activation, double *out, int ld_out);
+int launch_mlp_forward_mean(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
+                            int n_layers, int activation, double *out, int ld_out, const double *mvec, double mean0,
+                            double *mu, bool *mean_done);
 int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,
                      int64_t rows, int64_t Mtotal, double *y);
 int launch_transpose_pad(b7_ctx *c, const double *Z, int n, int ldz, int z, double *Zt, int zpad, int nk);

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "gemm_f64.h"
+#include "exp_table.h"
 
 namespace {
 
@@ -213,6 +214,252 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- the same network with its weights RESIDENT in LDS (the usual DNGO shapes: every layer's padded weights together fit) --
+// mlp_forward_mfma_kernel re-stages every layer's weights for every 32 inputs (two block barriers per 64-unit chunk, an
+// integer division per staged element) and calls ocml's tanh: one block took 26 us, 65 536 candidates 146 us
+// (profiles/r03_cfg5_kernel_stats_before.csv).  Here a block of eight waves stages all layers once ([npad][kpad + 1] per
+// layer, zero padded, odd stride) and then loops over 16-input tiles, one tile per wave at a time, with no block barrier
+// after the staging: a wave loads its tile's A fragments into registers, so the layer's outputs overwrite its inputs in the
+// wave's own [16][as] LDS strip; tanh is 1 - 2 / (e^{2|x|} + 1) with the table exponential of the covariance kernel
+// (expm1 form below: no cancellation near zero).  The epilogue writes the z real feature columns (the padding columns of
+// the feature matrix are zeroed once, when it is allocated) and, when the head's weights m are given, the posterior mean
+// mean0 + phi . m of each input (models/dngo.lua:174's predictive mean; otherwise a second pass over the features).
+__constant__ double exp2_tab_blr[256];   // [0, 128): 2^(j/128);  [128, 256): 2^(j/128) - 1, correctly rounded
+
+// tanh|x| = t / (t + 2) with t = e^{2|x|} - 1:  n = rint(y 128/ln2) for y = 2|x| <= 45, r = y - n ln2/128, q = e^r - 1
+// (degree-5 Taylor, |r| <= ln2/256), s = 2^(n >> 7):  t = s T (1 + q) - 1 = fma(s T, q, s T - 1), with (T - 1) taken from
+// its own table when s = 1 (no cancellation for small arguments); the quotient by reciprocal estimate, two Newton steps
+// and one correction (the compiler's IEEE division sequence is twice as long).  Against long-double tanh over 2e7 arguments
+// in [1e-8, 30]: relative error <= 5.1 * 2^-53.  tab: the 256-entry table above, copied to LDS by the kernel.
+// tanh of four values, stage by stage (cf. amp_exp_nonpos4 in covar.hip: one chain is ~30 dependent fp64 instructions, and
+// the compiler emits independent chains one after the other unless it is stopped)
+#define B7_STAGE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void tanh_fast4(const double (&x)[4], const double *__restrict__ tab, double (&out)[4]) {
+  double y[4], nb[4], nf[4], r[4], p[4], q[4], tj[4], tm1[4], st[4], t[4], d[4], rc[4], e[4];
+  int n[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = 2.0 * __builtin_fabs(x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = (y[i] > 45.0) ? 45.0 : y[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nb[i] = __builtin_fma(y[i], B7_EXP_INV, B7_EXP_MAGIC);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    n[i] = __double2loint(nb[i]);
+    tj[i] = tab[n[i] & 127];
+    tm1[i] = tab[128 + (n[i] & 127)];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nf[i] = nb[i] - B7_EXP_MAGIC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fma(nf[i], -B7_EXP_HEAD, y[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fma(nf[i], -B7_EXP_TAIL, r[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(r[i], 1.0 / 120.0, 1.0 / 24.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(p[i], r[i], 1.0 / 6.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(p[i], r[i], 0.5);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = __builtin_fma(p[i], r[i], 1.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = r[i] * p[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st[i] = __builtin_ldexp(tj[i], n[i] >> 7);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tm1[i] = ((n[i] >> 7) == 0) ? tm1[i] : st[i] - 1.0;
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __builtin_fma(st[i], q[i], tm1[i]);   // e^y - 1
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = t[i] + 2.0;
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rc[i] = __builtin_amdgcn_rcp(d[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-d[i], rc[i], 1.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rc[i] = __builtin_fma(e[i], rc[i], rc[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-d[i], rc[i], 1.0);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rc[i] = __builtin_fma(e[i], rc[i], rc[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = t[i] * rc[i];
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_fma(-d[i], q[i], t[i]);
+  B7_STAGE();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = __builtin_fma(e[i], rc[i], q[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = __builtin_copysign(q[i], x[i]);
+}
+struct MlpResident {      // LDS layout (doubles), computed on the host
+  int w_off[4], b_off[4]; // layer l: weights [npad_l][ks_l], biases [npad_l]
+  int ks[4], kpad[4], npad[4];
+  int m_off;              // the head's weights (z entries), when the mean is fused; else unused
+  int tab_off;            // the 256-entry exponential table of tanh_fast
+  int act_off, as;        // eight strips [16][as]
+};
+// NT_MAX: 16-column tiles of the widest layer output (4: widths <= 64, 8: <= 128); ACT: the activation, compile-time
+template <int NT_MAX, int ACT>
+__global__ void __launch_bounds__(512)
+    mlp_resident_kernel(const double *__restrict__ X, int64_t M, int d, const double *__restrict__ net, int n_layers,
+                        int d0, int d1, int d2, int d3, int d4, MlpResident lay, double *__restrict__ out,
+                        int ld_out, const double *__restrict__ mvec, double mean0, double *__restrict__ mu) {
+  extern __shared__ __align__(16) double rsm[];
+  const int dims[5] = {d0, d1, d2, d3, d4};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  {  // every layer's weights and biases, once per block: a wave takes rows wave, wave + 8, ...; all loads of a batch of
+     // eight rows are issued before the first LDS store (a load -> store loop paid one memory round trip per row)
+    const double *w = net;
+    for (int l = 0; l < n_layers; ++l) {
+      const int nin = dims[l], nout = dims[l + 1], ks = lay.ks[l], kp = lay.kpad[l], np = lay.npad[l];
+      double *wl = rsm + lay.w_off[l], *bl = rsm + lay.b_off[l];
+      for (int half = 0; half < 2; ++half) {   // rows wave + 8 i, i < 8, then i in [8, 16) (layers wider than 64 only)
+        if (half * 64 >= np) break;
+        double v[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = wave + 8 * (i + 8 * half), k = lane + 64 * h;
+            v[i][h] = (r < nout && k < nin) ? w[(size_t)r * nin + k] : 0.0;
+          }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = wave + 8 * (i + 8 * half), k = lane + 64 * h;
+            if (r < np && k < kp) wl[r * ks + k] = v[i][h];
+          }
+      }
+      const double *bias = w + (size_t)nout * nin;
+      for (int r = tid; r < np; r += 512) bl[r] = (r < nout) ? bias[r] : 0.0;
+      w = bias + nout;
+    }
+    const int z = dims[n_layers];
+    if (mvec)
+      for (int k = tid; k < z; k += 512) rsm[lay.m_off + k] = mvec[k];
+    if (tid < 256) rsm[lay.tab_off + tid] = exp2_tab_blr[tid];
+  }
+  __syncthreads();
+  const double *tab = rsm + lay.tab_off;
+  double *act = rsm + lay.act_off + wave * 16 * lay.as;
+  const int as = lay.as, z = dims[n_layers];
+  const int64_t ntiles = (M + 15) / 16;
+  // the inputs of a tile are fetched one tile ahead (a wave has one tile in flight and a global round trip at its start was
+  // a fifth of the tile's time): lane (lr, lq) holds columns lq, lq + 4, ... of row lr, up to 8 of them (d <= 32), else the
+  // strip is filled directly
+  const int kin = (d + 3) & ~3;
+  const bool pre_ok = kin <= 32;
+  double xin[8];
+  auto fetch = [&](int64_t t) {
+    int64_t g = t * 16 + lr;
+    if (g > M - 1) g = M - 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lq + 4 * i;
+      xin[i] = (k < d) ? X[g * d + k] : 0.0;
+    }
+  };
+  const int64_t tile0 = (int64_t)blockIdx.x * 8 + wave, tstep = (int64_t)gridDim.x * 8;
+  if (pre_ok && tile0 < ntiles) fetch(tile0);
+  for (int64_t tile = tile0; tile < ntiles; tile += tstep) {
+    const int64_t g0 = tile * 16;
+    if (pre_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (lq + 4 * i < kin) act[lr * as + lq + 4 * i] = xin[i];
+      if (tile + tstep < ntiles) fetch(tile + tstep);
+    } else {  // wide inputs: zero padded to a multiple of 4 columns, straight into the strip
+      int64_t g = g0 + lr;
+      if (g > M - 1) g = M - 1;
+      for (int k = lq; k < kin; k += 4) act[lr * as + k] = (k < d) ? X[g * d + k] : 0.0;
+    }
+    for (int l = 0; l < n_layers; ++l) {
+      const int nout = dims[l + 1], ks = lay.ks[l], ksteps = lay.kpad[l] >> 2, ntl = lay.npad[l] >> 4;
+      const double *wl = rsm + lay.w_off[l], *bl = rsm + lay.b_off[l];
+      // all n-tiles of the layer at once: NT_MAX independent accumulator chains, A and B fragments straight from LDS one
+      // k-step ahead of their MFMAs; tiles beyond the layer's last recompute its last tile and are dropped.  Every read
+      // of the strip precedes every write (one wave, program order), so the outputs overwrite the inputs in place.
+      const double *pa = act + lr * as + lq;
+      const double *pb[NT_MAX];
+#pragma unroll
+      for (int q = 0; q < NT_MAX; ++q) pb[q] = wl + ((q < ntl ? q : ntl - 1) * 16 + lr) * ks + lq;
+      d4_t c[NT_MAX];
+#pragma unroll
+      for (int q = 0; q < NT_MAX; ++q) c[q] = d4_t{0.0, 0.0, 0.0, 0.0};
+      double acur = pa[0], bcur[NT_MAX];
+#pragma unroll
+      for (int q = 0; q < NT_MAX; ++q) bcur[q] = pb[q][0];
+      for (int k4 = 0; k4 < ksteps; ++k4) {
+        const int kn = (k4 + 1 < ksteps) ? 4 * (k4 + 1) : 4 * k4;   // the last step re-reads itself
+        const double anxt = pa[kn];
+        double bnxt[NT_MAX];
+#pragma unroll
+        for (int q = 0; q < NT_MAX; ++q) bnxt[q] = pb[q][kn];
+#pragma unroll
+        for (int q = 0; q < NT_MAX; ++q) c[q] = mfma_f64(acur, bcur[q], c[q]);
+        acur = anxt;
+#pragma unroll
+        for (int q = 0; q < NT_MAX; ++q) bcur[q] = bnxt[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NT_MAX; ++q)
+        if (q < ntl) {
+          const int col = q * 16 + lr;
+          const double bv = bl[col];
+          double pre[4], post[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pre[r] = c[q][r] + bv;
+          if (ACT == 1) {
+            tanh_fast4(pre, tab, post);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              post[r] = ACT == 2 ? (pre[r] > 0.0 ? pre[r] : 0.0) : ACT == 3 ? 1.0 / (1.0 + exp(-pre[r])) : pre[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) act[(lq + 4 * r) * as + col] = (col < nout) ? post[r] : 0.0;
+        }
+    }
+    // features: the z real columns of 16 rows; all LDS reads of a 64-column slice first, then the stores
+    for (int kb = 0; kb < z; kb += 64) {
+      const int k = kb + lane;
+      double v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (k < z) ? act[r * as + k] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (k < z && g0 + r < M) out[(g0 + r) * ld_out + k] = v[r];
+    }
+    if (mvec) {  // posterior mean: four partial sums per row (k = part mod 4), folded in a fixed order
+      const double *mv = rsm + lay.m_off;
+      double sacc = 0.0;
+      for (int k = lq; k < z; k += 4) sacc = __builtin_fma(act[lr * as + k], mv[k], sacc);
+      sacc += __shfl_xor(sacc, 16);
+      sacc += __shfl_xor(sacc, 32);
+      if (lq == 0 && g0 + lr < M) mu[g0 + lr] = mean0 + sacc;
+    }
+  }
+}
+
 // y[row] = base + sum_k A[row][k] x[k]  (one wave per row)
 __global__ void __launch_bounds__(256)
     gemv_rows_kernel(const double *__restrict__ A, int lda, const double *__restrict__ x, int n, double base,
@@ -322,9 +569,23 @@ int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, co
   return B7_OK;
 }
 
-int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
-                       int n_layers, int activation, double *out, int ld_out) {
+// 2^(j/128) and 2^(j/128) - 1 for tanh_fast, uploaded once per process and device
+static int ensure_blr_tables(b7_ctx *c) {
+  static bool done[64] = {false};
+  if (c->device < 64 && done[c->device]) return B7_OK;
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_blr), B7_EXP2_TAB, sizeof(B7_EXP2_TAB), 0));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_blr), B7_EXP2M1_TAB, sizeof(B7_EXP2M1_TAB), sizeof(B7_EXP2_TAB)));
+  if (c->device < 64) done[c->device] = true;
+  return B7_OK;
+}
+
+// mvec (nullable, device, z entries) + mean0: also write mu[i] = mean0 + phi_i . mvec (only the resident-weights kernel does
+// that; *mean_done tells the caller whether it happened)
+int launch_mlp_forward_mean(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
+                            int n_layers, int activation, double *out, int ld_out, const double *mvec, double mean0,
+                            double *mu, bool *mean_done) {
   PhaseScope ps(c, "basis");
+  if (mean_done) *mean_done = false;
   if (n_layers < 1 || n_layers > 4) return b7_fail(c, B7_ERR_UNSUPPORTED, "mlp: 1..4 weighted layers supported");
   int dd[5] = {0, 0, 0, 0, 0};
   for (int i = 0; i <= n_layers; ++i) {
@@ -335,7 +596,48 @@ int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const doubl
   if (M <= 0) return B7_OK;
   int maxw = 0;
   for (int i = 0; i <= n_layers; ++i) maxw = dd[i] > maxw ? dd[i] : maxw;
-  if (maxw <= 128) {  // MFMA path
+  {  // resident weights when all layers + eight activation strips fit the CU's LDS
+    MlpResident lay{};
+    int off = 0, maxk = 0, maxn = 0;
+    for (int l = 0; l < n_layers; ++l) {
+      lay.kpad[l] = (dd[l] + 3) & ~3;
+      lay.npad[l] = (dd[l + 1] + 15) & ~15;
+      lay.ks[l] = lay.kpad[l] + 1;
+      lay.w_off[l] = off;
+      off += lay.npad[l] * lay.ks[l];
+      lay.b_off[l] = off;
+      off += lay.npad[l];
+      maxk = lay.kpad[l] > maxk ? lay.kpad[l] : maxk;
+      maxn = lay.npad[l] > maxn ? lay.npad[l] : maxn;
+    }
+    lay.m_off = off;
+    off += (dd[n_layers] + 1) & ~1;
+    lay.tab_off = off;
+    off += 256;
+    lay.as = (maxn > maxk ? maxn : maxk) + 1;
+    lay.act_off = off;
+    off += 8 * 16 * lay.as;
+    const size_t lds = sizeof(double) * (size_t)off;
+    if (lds <= 160 * 1024 && maxn <= 128) {
+      B7_TRY(ensure_blr_tables(c));
+      const int64_t ntiles = (M + 15) / 16;
+      int64_t blocks = (ntiles + 7) / 8;
+      if (blocks > c->cus) blocks = c->cus;   // persistent: one block per CU stages the weights once
+      using Kern = void (*)(const double *, int64_t, int, const double *, int, int, int, int, int, int, MlpResident, double *, int,
+                            const double *, double, double *);
+      static const Kern kerns[2][4] = {
+          {mlp_resident_kernel<4, 0>, mlp_resident_kernel<4, 1>, mlp_resident_kernel<4, 2>, mlp_resident_kernel<4, 3>},
+          {mlp_resident_kernel<8, 0>, mlp_resident_kernel<8, 1>, mlp_resident_kernel<8, 2>, mlp_resident_kernel<8, 3>}};
+      const Kern kern = kerns[maxn <= 64 ? 0 : 1][activation >= 0 && activation <= 3 ? activation : 0];
+      B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, c->stream, X, M, d, net_dev, n_layers, dd[0], dd[1], dd[2],
+                         dd[3], dd[4], lay, out, ld_out, mvec, mean0, mu);
+      B7_HIP(c, hipGetLastError());
+      if (mean_done) *mean_done = mvec != nullptr;
+      return B7_OK;
+    }
+  }
+  if (maxw <= 128) {  // MFMA path, weights staged per layer chunk
     const int stride = ((maxw + 15) & ~15) + 1;
     const int lds = (64 + 64) * stride * (int)sizeof(double);
     B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_mfma_kernel),
@@ -353,6 +655,11 @@ int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const doubl
                      d, net_dev, n_layers, dd[0], dd[1], dd[2], dd[3], dd[4], activation, stride, out, ld_out);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
+}
+
+int launch_mlp_forward(b7_ctx *c, const double *X, int64_t M, int d, const double *net_dev, const int *dims,
+                       int n_layers, int activation, double *out, int ld_out) {
+  return launch_mlp_forward_mean(c, X, M, d, net_dev, dims, n_layers, activation, out, ld_out, nullptr, 0.0, nullptr, nullptr);
 }
 
 int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n, double base, int64_t row0,

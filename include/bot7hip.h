@@ -323,6 +323,17 @@ typedef struct {
 int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset,
                      double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
 
+/* bayesopt:eval's DNGO branch + nominate as ONE call (bots/bayesopt.lua:65-66, :96 over models/dngo.lua:155-175):
+ * b7_blr_fit_x(net, X0, Y0, ...) + b7_blr_basis(net, resident grid) + b7_blr_predict + the acquisition of `spec` (written,
+ * not accumulated: this branch has no hyper marginalisation) + b7_score_finish_global, enqueued back to back with ONE host
+ * synchronisation; the candidates' features are recomputed on every call, as the reference does.  Results as the separate
+ * calls (the posterior mean comes out of the feature kernel itself: its last bits may differ from b7_blr_predict's).
+ * best_idx1 / global_row_offset / communicator as b7_eval_nominate.  jitter_used (nullable): 0, or < 0 when the head's
+ * Cholesky needed utils.math.chol's jitter schedule and the fit was redone through b7_blr_fit_x. */
+int b7_blr_eval_nominate(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec,
+                         double beta, double mean, const b7_score_spec *spec, int64_t global_row_offset, double *best_val,
+                         int64_t *best_idx1, double *jitter_used);
+
 /* ---- one process, several GPUs: the reference's single-process trial loop over a sharded grid ----------------- *
  * The reference is ONE LuaJIT process (bots/abstract.lua:155-169); a group lets that one process drive n GPUs, so the
  * trial loop, Torch's RNG stream and the single evaluation of the user's objective per trial (bots/abstract.lua:124)

@@ -1450,6 +1450,40 @@ def test_full_shape_cfg5(ctx, orc):
                                                                                  np.max(np.abs(ei - want))))
     assert wv > 1e-3, "EI at the winner should be O(1e-2 .. 1), not an underflow"
     assert idx == wi and val == pytest.approx(wv, rel=1e-6)
+    # the same nomination as ONE call (b7_blr_eval_nominate): the oracle's winner, the separate calls' value; its scores
+    # (left in the accumulator) against the oracle over the whole grid
+    v1, i1, jit = ctx.blr_eval_nominate(W, b, "Tanh", X_obs, Y, alpha_p, beta, ymean, score="ei", fmin=[float(Y.min())],
+                                        want_jitter=True)
+    assert i1 == wi and v1 == pytest.approx(wv, rel=1e-6) and jit == 0.0
+    _, _, ei1 = ctx.score_finish(1.0, download=True)
+    assert np.max(np.abs(ei1 - want)) < 1e-9 * max(1.0, np.abs(want).max())
+    v2, i2 = ctx.blr_eval_nominate(W, b, "Tanh", X_obs, Y, alpha_p, beta, ymean, score="cb")
+    cbw = orc.c.cb(mu_all, var_all)
+    assert i2 == orc.c.argmax_first(cbw)[0]
+
+
+def test_blr_eval_nominate_small_shapes_and_activations(ctx, orc):
+    """b7_blr_eval_nominate over the shapes of test_dngo_basis_and_blr_head_match_oracle (Tanh with resident weights, ReLU
+    with one wide layer, Sigmoid at d = 32) and a ragged grid: winner and scores equal the oracle's."""
+    from oracle import blr
+    from conftest import make_network
+    for d, widths, act, N, M in [(6, (50, 50, 50), "Tanh", 80, 3000), (2, (100,), "ReLU", 24, 257),
+                                 (32, (64, 100), "Sigmoid", 300, 1000), (3, (20, 20), "Tanh", 10, 17)]:
+        W, b = make_network(d, widths, seed=d)
+        X_obs, Y, X_hid, _ = make_problem(ctx, orc, d, N, M, lambda X: np.sin(3 * X.sum(axis=1, keepdims=True)))
+        alpha_p, beta, mean = 2.0, 1.0 / (1e-2 * float(np.var(Y))), float(np.mean(Y))
+        ctx.grid_upload(X_hid)
+        Z1 = ctx.blr_basis(W, b, act, download=True)
+        assert np.allclose(Z1, blr.basis(X_hid, W, b, act), rtol=1e-12, atol=1e-13), (d, act)
+        f = blr.fit(blr.basis(X_obs, W, b, act), Y, alpha_p, beta, mean)
+        mu_o, var_o = blr.predict(f, blr.basis(X_hid, W, b, act))
+        for kw, want in (({"score": "ei", "fmin": [float(Y.min())]}, orc.c.ei(mu_o, var_o, [float(Y.min())])),
+                         ({"score": "cb"}, orc.c.cb(mu_o, var_o))):
+            v, i = ctx.blr_eval_nominate(W, b, act, X_obs, Y, alpha_p, beta, mean, **kw)
+            wi, wv = orc.c.argmax_first(want)
+            _, _, got = ctx.score_finish(1.0, download=True)
+            assert np.allclose(got, want, rtol=1e-5, atol=1e-10), (d, act, kw["score"])
+            assert i == wi and v == pytest.approx(wv, rel=1e-6, abs=1e-12), (d, act, kw["score"])
 
 
 # ---- the persistent Cholesky schedule (potrf_persist.hip): same bits as the launch schedule, also under load ----------
