@@ -20,7 +20,7 @@ ERR_NAMES = {-1: "B7_ERR_INVALID", -2: "B7_ERR_HIP", -3: "B7_ERR_NOMEM", -4: "B7
 SYMBOLS = [
     "b7_abi_version", "b7_create", "b7_destroy", "b7_last_error", "b7_device_info", "b7_sync", "b7_set_workspace",
     "b7_sobol_direction_numbers", "b7_grid_sobol", "b7_grid_random", "b7_grid_upload", "b7_grid_download", "b7_grid_shape", "b7_grid_remove", "b7_grid_remove_rows",
-    "b7_grid_colrange", "b7_grid_apply_onesided",
+    "b7_grid_colrange", "b7_grid_apply_onesided", "b7_grid_random_torch", "b7_torch_rand",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_predict_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
     "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global", "b7_eval_nominate", "b7_blr_eval_nominate",
@@ -136,6 +136,8 @@ def load():
                                    vp, vp]),
         "b7_blr_eval_nominate": (i32, [vp, C.POINTER(Mlp), vp, vp, i32, dbl, dbl, dbl, C.POINTER(ScoreSpec), i64, C.POINTER(dbl),
                                        C.POINTER(i64), C.POINTER(dbl)]),
+        "b7_grid_random_torch": (i32, [vp, i64, i32, C.c_uint64, i32, vp, vp, vp]),
+        "b7_torch_rand": (i32, [C.c_uint64, i64, i32, vp]),
         "b7_grid_colrange": (i32, [vp, vp, vp]),
         "b7_grid_apply_onesided": (i32, [vp, vp, vp, vp]),
         "b7_nominate_commit": (i32, [vp, i64, C.POINTER(i64), vp]),
@@ -257,6 +259,15 @@ class Context(object):
         out = np.empty((size, dims), dtype=np.float64) if download else None
         self._ck(self._L.b7_grid_random(self._h, int(size), int(dims), int(seed) & (2 ** 64 - 1), int(row_offset),
                                         _ptr(mn), _ptr(mx), _ptr(out)))
+        self.grid_version += 1
+        return out
+
+    def grid_random_torch(self, size, dims, seed=0, resolution=32, mins=None, maxes=None, download=True):
+        """grids/random.lua with torch.rand's own MT19937 stream (torch.manualSeed(seed))."""
+        mn, mx = self._minmax(mins, maxes, dims)
+        out = np.empty((size, dims), dtype=np.float64) if download else None
+        self._ck(self._L.b7_grid_random_torch(self._h, int(size), int(dims), int(seed), int(resolution), _ptr(mn), _ptr(mx),
+                                              _ptr(out)))
         self.grid_version += 1
         return out
 
@@ -795,6 +806,15 @@ class Group(object):
         self._ck(self._L.b7_group_nominate_commit(self._h, int(idx1_global), _ptr(row)))
         self.grid_version += 1
         return row
+
+
+def torch_rand(seed, n, resolution=32):
+    """torch.manualSeed(seed); torch.rand(n) -- MT19937, host-only."""
+    out = np.empty(int(n), dtype=np.float64)
+    rc = load().b7_torch_rand(int(seed), int(n), int(resolution), _ptr(out))
+    if rc != B7_OK:
+        raise Bot7HipError(rc, "resolution must be 32 or 53")
+    return out
 
 
 def shard_commit_rule(idx1_global, offset, M_local):

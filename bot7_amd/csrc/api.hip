@@ -308,6 +308,77 @@ int b7_grid_random(b7_ctx *c, int64_t size, int dims, uint64_t seed, int64_t row
   return grid_copy_out(c, out_host);
 }
 
+// ---- torch.rand's own stream (grids/random.lua:24) ---------------------------------------------------------------------
+// Torch7's CPU generator is MT19937 (TH/THRandom.c) [public knowledge, not in the reference tree]: manualSeed(s) is
+// init_genrand(s), THRandom_random the tempered 32-bit output, and torch.rand fills a tensor in row-major order.  Two
+// generations of TH differ in how a double is made from it: `resolution` 32 is THRandom_uniform's
+// random() * 2^-32 (Torch7 up to 2017, the era of bot7), 53 the later ((random64() & (2^53 - 1)) * 2^-53 with
+// random64 = (random() << 32) | random().  Sequential by construction, so it runs on the host (33M draws take 0.1 s) and
+// only the affine map of grids/random.lua:27-33 runs on the device.
+namespace {
+struct Mt19937 {
+  uint32_t mt[624];
+  int idx;
+  explicit Mt19937(uint32_t seed) {
+    mt[0] = seed;
+    for (int j = 1; j < 624; ++j) mt[j] = 1812433253u * (mt[j - 1] ^ (mt[j - 1] >> 30)) + (uint32_t)j;
+    idx = 624;
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int k = 0; k < 624; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+};
+}  // namespace
+
+int b7_torch_rand(uint64_t seed, int64_t n, int resolution, double *out) {
+  if (n < 0 || (n > 0 && !out) || (resolution != 32 && resolution != 53)) return B7_ERR_INVALID;
+  Mt19937 g((uint32_t)seed);
+  if (resolution == 32)
+    for (int64_t i = 0; i < n; ++i) out[i] = (double)g.next() * (1.0 / 4294967296.0);
+  else
+    for (int64_t i = 0; i < n; ++i) {
+      const uint64_t hi = g.next(), lo = g.next();
+      out[i] = (double)(((hi << 32) | lo) & ((1ull << 53) - 1)) * 1.1102230246251565404e-16;
+    }
+  return B7_OK;
+}
+
+int b7_grid_random_torch(b7_ctx *c, int64_t size, int dims, uint64_t seed, int resolution, const double *mins,
+                         const double *maxes, double *out_host) {
+  if (!c) return B7_ERR_INVALID;
+  if (size < 0 || (resolution != 32 && resolution != 53))
+    return b7_fail(c, B7_ERR_INVALID, "random grid (torch stream): size >= 0, resolution 32 or 53");
+  std::vector<double> u((size_t)size * (dims > 0 ? dims : 0));
+  if (dims >= 1 && b7_torch_rand(seed, (int64_t)u.size(), resolution, u.data()) != B7_OK)
+    return b7_fail(c, B7_ERR_INVALID, "random grid (torch stream): bad arguments");
+  B7_TRY(b7_grid_upload(c, u.data(), size, dims));
+  if (mins && maxes && size > 0) {   // grids/random.lua:27-28: cmul by (maxes + -mins), then add mins: two rounded operations
+    double *stage = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 8192);
+    double *v_dev = (double *)((char *)c->scratch.p + 8192 + 4096);
+    for (int pass = 0; pass < 2; ++pass) {
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+      for (int k = 0; k < dims; ++k) stage[k] = pass == 0 ? maxes[k] + (-mins[k]) : mins[k];
+      B7_HIP(c, hipMemcpyAsync(v_dev, stage, sizeof(double) * dims, hipMemcpyHostToDevice, c->stream));
+      B7_TRY(launch_col_affine(c, cur_grid(c), c->M, dims, v_dev, pass == 0));
+    }
+  } else if (mins || maxes) {
+    B7_TRY(onesided(c, mins, maxes));
+  }
+  return grid_copy_out(c, out_host);
+}
+
 int b7_grid_colrange(b7_ctx *c, double *col_min, double *col_max) {
   if (!c) return B7_ERR_INVALID;
   if (c->M <= 0) return b7_fail(c, B7_ERR_STATE, "grid_colrange: no candidate grid on this context");

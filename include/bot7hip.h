@@ -75,6 +75,17 @@ int b7_sobol_direction_numbers(int dims, uint32_t *out);
 int b7_grid_random(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins,
                    const double *maxes, double *out_host);
 
+/* grids/random.lua:23-35 with torch.rand's OWN stream, for replaying a reference run point for point: Torch7's CPU generator
+ * is MT19937 seeded by torch.manualSeed(seed) (TH/THRandom.c; not part of the reference tree, restated from its published
+ * algorithm: parity unpinned).  resolution 32: a double is random() * 2^-32 (Torch7 of bot7's era); 53: the later
+ * (random64() & (2^53 - 1)) * 2^-53.  The stream is sequential, so the uniforms are made on the host and uploaded; the
+ * affine map (both / one / none of mins, maxes) runs on the device as for b7_grid_random.  No row_offset: a rank that owns
+ * rows [lo, hi) of a grid made this way generates the whole stream and uploads its slice (b7_torch_rand + b7_grid_upload). */
+int b7_grid_random_torch(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int resolution, const double *mins,
+                         const double *maxes, double *out_host);
+/* Host-only: n doubles of that stream (what torch.manualSeed(seed); torch.rand(n) returns). */
+int b7_torch_rand(uint64_t seed, int64_t n, int resolution, double *out);
+
 /* The pieces of the one-sided maps, for callers that combine shards themselves: grid:min(1) / grid:max(1) of the resident
  * grid (both nullable, d entries), and the map itself given the extremes of the whole grid (exactly one of mins / maxes). */
 int b7_grid_colrange(b7_ctx *ctx, double *col_min, double *col_max);

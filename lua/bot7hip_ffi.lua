@@ -22,6 +22,8 @@ int b7_set_workspace(b7_ctx *ctx, int64_t bytes);
 int b7_grid_sobol(b7_ctx *ctx, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes, double *out_host);
 int b7_sobol_direction_numbers(int dims, uint32_t *out);
 int b7_grid_random(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins, const double *maxes, double *out_host);
+int b7_grid_random_torch(b7_ctx *ctx, int64_t size, int dims, uint64_t seed, int resolution, const double *mins, const double *maxes, double *out_host);
+int b7_torch_rand(uint64_t seed, int64_t n, int resolution, double *out);
 int b7_grid_colrange(b7_ctx *ctx, double *col_min, double *col_max);
 int b7_grid_apply_onesided(b7_ctx *ctx, const double *mins, const double *maxes, const double *col_ext);
 int b7_grid_upload(b7_ctx *ctx, const double *X_hid, int64_t M, int d);

@@ -320,3 +320,38 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
                          env=dict(os.environ, B7_RCCL_LIB="/nonexistent/librccl-not-here.so"))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "code -7" in out.stdout and "librccl-not-here" in out.stdout, out.stdout
+
+
+# ---- torch.rand's own stream for grids/random.lua (MT19937) ---------------------------------------------------------------
+def test_torch_rand_stream_known_answers():
+    """MT19937 known answers [public knowledge]: with the reference seed 5489 the first outputs are 3499211612, 581869302,
+    3890346734, 3586334585, 545404204 and the 10000th is 4123659995 (Matsumoto & Nishimura's mt19937ar.c / C++11 [rand.predef]);
+    numpy's legacy seeding is the same init_genrand, so RandomState(seed).randint / random_sample give independent checks of
+    both resolutions."""
+    from bot7_amd import _lib
+    u = _lib.torch_rand(5489, 10000, 32)
+    first = (u[:5] * 4294967296.0).astype(np.uint64)
+    assert list(first) == [3499211612, 581869302, 3890346734, 3586334585, 545404204]
+    assert int(u[9999] * 4294967296.0) == 4123659995
+    for seed in (0, 1, 123456789):
+        rs = np.random.RandomState(seed)
+        raw = rs.randint(0, 2 ** 32, size=64, dtype=np.uint64)
+        assert np.array_equal(_lib.torch_rand(seed, 64, 32), raw.astype(np.float64) / 4294967296.0)
+        hi, lo = raw[0::2], raw[1::2]
+        want53 = (((hi << np.uint64(32)) | lo) & np.uint64((1 << 53) - 1)).astype(np.float64) * 2.0 ** -53
+        assert np.array_equal(_lib.torch_rand(seed, 32, 53), want53)
+    with pytest.raises(_lib.Bot7HipError):
+        _lib.torch_rand(1, 4, 24)
+
+
+@pytest.mark.gpu
+def test_grid_random_with_the_torch_stream(ctx, orc):
+    from bot7_amd import _lib
+    size, dims = 257, 7
+    u = _lib.torch_rand(42, size * dims, 32).reshape(size, dims)
+    mins, maxes = np.linspace(-1, 1, dims), np.linspace(2, 5, dims)
+    assert np.array_equal(ctx.grid_random_torch(size, dims, seed=42), u)
+    assert np.array_equal(ctx.grid_random_torch(size, dims, seed=42, mins=mins, maxes=maxes), orc.c.affine(u, mins, maxes))
+    assert np.array_equal(ctx.grid_download(), orc.c.affine(u, mins, maxes))
+    assert np.array_equal(ctx.grid_random_torch(size, dims, seed=42, mins=mins), orc.c.affine(u, mins=mins))
+    assert np.array_equal(ctx.grid_random_torch(size, dims, seed=42, maxes=maxes), orc.c.affine(u, maxes=maxes))
