@@ -210,8 +210,9 @@ __global__ void __launch_bounds__(256)
   constexpr int dpad = DPAD, NCH = (DPAD / 2 + TPR - 1) / TPR, KSTEPS = DPAD / 4;
   constexpr int stride = DPAD + 1;  // odd: conflict-free for the fused ds_read2_b64 fragment reads (gemm_f64.h)
   (void)dpad_rt;
-  double *sq = sm;                          // KQ x stride
-  double *so = sq + KQ * stride;            // 2 x KO x stride
+  constexpr int SQS = stride > 32 ? stride : 32;  // the query tile's rows double as the waves' store-staging strips
+  double *sq = sm;                          // KQ x SQS (rows of `stride` doubles in use)
+  double *so = sq + KQ * SQS;               // 2 x KO x stride
   double *sh = so + 2 * KO * stride;        // 2 x KO   zs/2 of the slab
   double *sal = sh + 2 * KO;                // 2 x KO   alpha of the slab
   double *shq = sal + 2 * KO;               // KQ       xs/2 of the queries
@@ -323,6 +324,26 @@ __global__ void __launch_bounds__(256)
       for (int r = 0; r < 4; ++r) macc[r] = __builtin_fma(kv[r], al, macc[r]);
       // rows (lq, lq+4, lq+8, lq+12) x column lr  ->  16-byte stores of two adjacent columns: even lanes write rows r = 0
       // and 2 (their own value, then the odd neighbour's), odd lanes rows r = 1 and 3 (the even neighbour's, then their own)
+#if B7_KSX_ABLATE & 64
+      // Stores through an LDS transposition: the wave's strip of the query tile (dead since its fragments went to
+      // registers) takes two 16x16 tiles as [16][32] doubles, odd rows rotated by 16 columns (conflict-free writes); read
+      // back row-wise, one store instruction covers 4 rows x 256 contiguous bytes, and there is no lane-pair packing
+      {
+        double *tb = sq + wave * 16 * SQS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(lq + 4 * r) * 32 + (((t & 1) * 16 + lr + 16 * (lq & 1)) & 31)] = kv[r];
+        if (t & 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + lq, col = lr * 2, cs = (col + 16 * (row & 1)) & 31;
+            d2_t v;
+            v[0] = tb[row * 32 + cs];
+            v[1] = tb[row * 32 + cs + 1];
+            *reinterpret_cast<d2_t *>(out + ((int64_t)blockIdx.x * KQ + wave * 16 + row) * Npad + o0 + (t - 1) * 16 + col) = v;
+          }
+        }
+      }
+#else
       d2_t v01, v23;
       pair_pack(kv[0], kv[1], v01);
       pair_pack(kv[2], kv[3], v23);
@@ -346,6 +367,7 @@ __global__ void __launch_bounds__(256)
         }
 #endif
       }
+#endif
     }
     if (more) store_slab(cur ^ 1);
     __syncthreads();
@@ -384,7 +406,8 @@ __global__ void __launch_bounds__(256)
 
 size_t ksx_lds_bytes(int dpad) {
   const int KO = ksx_slab(dpad);
-  return sizeof(double) * ((size_t)(KQ + 2 * KO) * (dpad + 1) + 4 * KO + KQ + 128);
+  const int sqs = dpad + 1 > 32 ? dpad + 1 : 32;
+  return sizeof(double) * ((size_t)KQ * sqs + (size_t)2 * KO * (dpad + 1) + 4 * KO + KQ + 128);
 }
 
 // the 2^(j/128) table goes to constant memory once per process and device
