@@ -95,9 +95,13 @@ int exchange(b7_group *g) {
     }
     ncclResult_t e = r.GroupEnd();
     if (e != ncclSuccess) return gfail(g, B7_ERR_COMM, "ncclGroupEnd: %s", r.GetErrorString(e));
+    if (hipSetDevice(g->ctx[0]->device) != hipSuccess) return gfail(g, B7_ERR_HIP, "hipSetDevice(%d) failed", g->ctx[0]->device);
     G_TRY(g, 0, exch_fetch(g->ctx[0], 0, n));  // every member holds the whole table now: member 0's copy is read
   } else {
-    for (int i = 0; i < n; ++i) G_TRY(g, i, exch_fetch(g->ctx[i], i, 1));
+    for (int i = 0; i < n; ++i) {
+      if (hipSetDevice(g->ctx[i]->device) != hipSuccess) return gfail(g, B7_ERR_HIP, "hipSetDevice(%d) failed", g->ctx[i]->device);
+      G_TRY(g, i, exch_fetch(g->ctx[i], i, 1));
+    }
   }
   return B7_OK;
 }

@@ -355,3 +355,36 @@ def test_grid_random_with_the_torch_stream(ctx, orc):
     assert np.array_equal(ctx.grid_download(), orc.c.affine(u, mins, maxes))
     assert np.array_equal(ctx.grid_random_torch(size, dims, seed=42, mins=mins), orc.c.affine(u, mins=mins))
     assert np.array_equal(ctx.grid_random_torch(size, dims, seed=42, maxes=maxes), orc.c.affine(u, maxes=maxes))
+
+
+@pytest.mark.gpu
+def test_group_with_more_members_than_rows_and_shards_that_run_empty(ctx, orc):
+    """Five members, seven candidates: members 2..4 hold one row each, nominations keep working while shards empty out one by
+    one, down to the last candidate; every step equals the single context's; an empty group refuses to nominate."""
+    import bot7_amd
+    from harness import benchmarks
+    d, N, M = 2, 12, 7
+    rng = np.random.default_rng(21)
+    X_obs, X_hid = rng.random((N, d)), rng.random((M, d))
+    Y = benchmarks.braninhoo(X_obs)
+    amp = float(np.var(Y))
+    hyps = [dict(lenscale_sq=np.full(d, 0.3), amp=amp, noise=1e-4 * amp, mean=float(np.mean(Y)))]
+    g = bot7_amd.Group([0] * 5)
+    g.grid_upload(X_hid)
+    assert list(g.grid_shape()[2]) == [0, 2, 4, 5, 6, 7]
+    g.gp_set_data(X_obs, Y)
+    ctx.grid_upload(X_hid)
+    ctx.gp_set_data(X_obs, Y)
+    left = X_hid.copy()
+    for t in range(M):
+        want = ctx.eval_nominate(hyps, score="cb")
+        got = g.eval_nominate(hyps, score="cb")
+        assert got == want, "step %d" % t
+        row = g.nominate_commit(got[1])
+        assert np.array_equal(row, left[got[1] - 1]) and np.array_equal(ctx.nominate_commit(got[1], 0)[0], row)
+        left = np.delete(left, got[1] - 1, axis=0)
+        assert np.array_equal(g.grid_download(), left) if left.shape[0] else g.grid_shape()[0] == 0
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        g.eval_nominate(hyps, score="cb")
+    assert e.value.code == -4
+    g.close()
