@@ -13,6 +13,9 @@
 
 #include "gemm_f64.h"
 #include "exp_table.h"
+#ifndef B7_MLP_ABLATE
+#define B7_MLP_ABLATE 0
+#endif
 
 namespace {
 
@@ -392,7 +395,11 @@ __global__ void __launch_bounds__(512)
       if (g > M - 1) g = M - 1;
       for (int k = lq; k < kin; k += 4) act[lr * as + k] = (k < d) ? X[g * d + k] : 0.0;
     }
-    for (int l = 0; l < n_layers; ++l) {
+    // the layer loop is unrolled so that every layer's shape sits in its own scalar registers for the whole kernel: indexed
+    // by a run-time l, each field of `lay` was a scalar load from the argument block (and a wait) per layer per tile
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l >= n_layers) break;
       const int nout = dims[l + 1], ks = lay.ks[l], ksteps = lay.kpad[l] >> 2, ntl = lay.npad[l] >> 4;
       const double *wl = rsm + lay.w_off[l], *bl = rsm + lay.b_off[l];
       // all n-tiles of the layer at once: NT_MAX independent accumulator chains, A and B fragments straight from LDS one
@@ -408,7 +415,11 @@ __global__ void __launch_bounds__(512)
       double acur = pa[0], bcur[NT_MAX];
 #pragma unroll
       for (int q = 0; q < NT_MAX; ++q) bcur[q] = pb[q][0];
+#if B7_MLP_ABLATE & 2   // one k-step per layer
+      for (int k4 = 0; k4 < 1; ++k4) {
+#else
       for (int k4 = 0; k4 < ksteps; ++k4) {
+#endif
         const int kn = (k4 + 1 < ksteps) ? 4 * (k4 + 1) : 4 * k4;   // the last step re-reads itself
         const double anxt = pa[kn];
         double bnxt[NT_MAX];
@@ -439,6 +450,9 @@ __global__ void __launch_bounds__(512)
           for (int r = 0; r < 4; ++r) act[(lq + 4 * r) * as + col] = (col < nout) ? post[r] : 0.0;
         }
     }
+#if B7_MLP_ABLATE & 1   // diagnostic builds only (tools/basis_ablate.py): no feature stores
+    if (act[0] == 1.2345e-300)
+#endif
     // features: the z real columns of 16 rows; all LDS reads of a 64-column slice first, then the stores
     for (int kb = 0; kb < z; kb += 64) {
       const int k = kb + lane;

@@ -136,22 +136,38 @@ struct GemmF64 {
     }
   }
 
+  // The fragments of k-step s + 1 are requested BETWEEN the MFMAs of step s, one read behind each MFMA, in the order written
+  // (sched_barrier keeps the compiler from regrouping them): tools/mfma_feed_probe.hip measures 94 cycles per
+  // v_mfma_f64_16x16x4 for "read the step's fragments, then its MFMAs" with one wave per SIMD, 87 with the reads of the next
+  // step hoisted in front of this step's MFMAs, 75.5 with the reads interleaved like this (64 from registers).  The
+  // arithmetic and its order are untouched.
   __device__ static __forceinline__ void compute_stage(const double *__restrict__ sm, d4_t (&acc)[TM][TN]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const double *sa = sm + (wm * (BM / WM) + (lane & 15)) * STRIDE + (lane >> 4);
     const double *sb = sm + BM * STRIDE + (wn * (BN / WN) + (lane & 15)) * STRIDE + (lane >> 4);
+    constexpr int STEPS = BK / 4, NF = TM + TN;
+    double f[2][NF];  // fragments of a step: A strips first, then B strips
 #pragma unroll
-    for (int s = 0; s < BK / 4; ++s) {
-      double af[TM], bf[TN];
+    for (int q = 0; q < NF; ++q) f[0][q] = q < TM ? sa[q * 16 * STRIDE] : sb[(q - TM) * 16 * STRIDE];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = sa[i * 16 * STRIDE + 4 * s];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = sb[j * 16 * STRIDE + 4 * s];
+    for (int s = 0; s < STEPS; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      int q = 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = mfma_f64(f[cur][i], f[cur][TM + j], acc[i][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < STEPS && q < NF) {
+            f[nxt][q] = q < TM ? sa[q * 16 * STRIDE + 4 * (s + 1)] : sb[(q - TM) * 16 * STRIDE + 4 * (s + 1)];
+            ++q;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (s + 1 < STEPS)
+        for (; q < NF; ++q) f[nxt][q] = q < TM ? sa[q * 16 * STRIDE + 4 * (s + 1)] : sb[(q - TM) * 16 * STRIDE + 4 * (s + 1)];
     }
   }
 
