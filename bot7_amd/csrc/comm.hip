@@ -56,7 +56,7 @@ Rccl &rccl() {
 int exch_table_ensure(b7_ctx *c, int world) {
   if (world < 1 || world > B7_MAX_WORLD) return b7_fail(c, B7_ERR_UNSUPPORTED, "exchange: world %d not in [1, %d]", world, B7_MAX_WORLD);
   B7_TRY(b7_ensure(c, c->slots, sizeof(uint64_t) * B7_TAB_W * (size_t)world + sizeof(double) * 128 + 64));
-  if (!c->tab_host) B7_HIP(c, hipHostMalloc((void **)&c->tab_host, sizeof(uint64_t) * B7_TAB_W * B7_MAX_WORLD, hipHostMallocDefault));
+  if (!c->tab_host) B7_HIP(c, hipHostMalloc((void **)&c->tab_host, sizeof(uint64_t) * B7_TAB_W * (B7_MAX_WORLD + 1), hipHostMallocDefault));  // + one staging record
   return B7_OK;
 }
 
@@ -74,7 +74,7 @@ int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, b
 // every rank returns an error together instead of the others waiting in ncclAllReduce for ever.
 int exch_fail_record(b7_ctx *c, int rank, int world, int code) {
   B7_TRY(exch_table_ensure(c, world));
-  uint64_t *stage = c->tab_host + (size_t)(B7_MAX_WORLD - 1) * B7_TAB_W;  // last record of the pinned block: staging
+  uint64_t *stage = c->tab_host + (size_t)B7_MAX_WORLD * B7_TAB_W;  // the record behind the table's host copy: staging
   B7_HIP(c, hipStreamSynchronize(c->stream));
   memset(stage, 0, sizeof(uint64_t) * B7_TAB_W);
   stage[B7_TAB_STATUS] = (uint64_t)(int64_t)(code < 0 ? -code : 1);
@@ -142,7 +142,7 @@ int exch_conclude(b7_ctx *c, const uint64_t *tab, int world, double *best_val, i
   c->win_valid = true;
   c->win_idx1 = i;
   c->win_rank = wr;
-  c->win_d = c->d;
+  c->win_d = c->d > 0 ? c->d : c->dfit;
   memcpy(c->win_row, &tab[(size_t)wr * B7_TAB_W + B7_TAB_ROW0], sizeof(double) * B7_MAX_D);
   c->shard_world = world;
   for (int r = 0; r < world; ++r) c->shard_rows[r] = (int64_t)tab[(size_t)r * B7_TAB_W + B7_TAB_ROWS];
@@ -297,7 +297,7 @@ int b7_nominate_commit(b7_ctx *c, int64_t idx1_global, int64_t *global_row_offse
   if (b7_shard_commit_rule(idx1_global, *global_row_offset, c->M, &local, &new_off) != B7_OK)
     return b7_fail(c, B7_ERR_INVALID, "nominate_commit: index %lld, offset %lld", (long long)idx1_global, (long long)*global_row_offset);
   B7_HIP(c, hipSetDevice(c->device));
-  const int d = c->d;
+  const int d = c->d > 0 ? c->d : c->dfit;  // a rank that never made its (empty) shard still learns the row's width from the data
   // the row: every rank already holds it when idx is the winner of the last exchange (the model-based trials);
   // otherwise (the random initial trials, bots/bayesopt.lua:90-91) the owner broadcasts it with one more all-reduce.
   // Every rank takes the same branch: they all saw the same exchange and are all told the same idx.

@@ -66,14 +66,14 @@ def _cfg1_grid():
     return np.random.default_rng(11).random((256, 2))
 
 
-def _run_bot(cand, model_ctx, trials, nSamples=2):
+def _run_bot(cand, model_ctx, trials, nSamples=2, sample=False):
     """`trials` trials of the harness bot (harness/bots: the reference's run_trial, statement for statement) over the given
     candidate set -> (nominees, responses, best)."""
     import bot7_amd
     from harness import benchmarks, bots
     cfg = {"bot": {"verbose": 0, "budget": trials, "nInitial": 2, "nSamples": nSamples, "seed": 4},
            "grid": {"type": "random", "size": 256, "dims": 2}, "score": {"type": "expected_improvement"}}
-    model = bot7_amd.models.gp_regressor({}, context=model_ctx)
+    model = bot7_amd.models.gp_regressor({"sample": True, "nBurnin": 1, "seed": 5} if sample else {}, context=model_ctx)
     bot = bots.bayesopt(benchmarks.braninhoo, [H("x1"), H("x2")], cfg, cache={"candidates": cand, "model": model})
     xs = []
     for _ in range(trials):
@@ -388,3 +388,62 @@ def test_group_with_more_members_than_rows_and_shards_that_run_empty(ctx, orc):
         g.eval_nominate(hyps, score="cb")
     assert e.value.code == -4
     g.close()
+
+
+# ---- several PROCESSES, one GPU: the per-process communicator path with a test double for RCCL's transport ----------------
+def _stub_lib():
+    """tests/stub/rccl_shm_stub.cpp -> tests/stub/_build/librccl_shm_stub.so (hipcc; also built by __graft_entry__.build)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "stub", "rccl_shm_stub.cpp")
+    out = os.path.join(ROOT, "tests", "stub", "_build", "librccl_shm_stub.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-I/opt/rocm/include", "-o", out, src,
+                               "-Wl,-rpath,/opt/rocm/lib", "-lrt"])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,sample", [(2, False), (3, True)])
+def test_processes_sharing_the_gpu_run_the_trial_loop_through_the_communicator_path(ctx, world, sample, tmp_path):
+    """The one-process-per-GPU layout for real, as far as one GPU allows: `world` processes, each with its own context on cuda:0
+    and a communicator from b7_comm_init, run 7 trials of cfg1 in lock step through b7_eval_nominate (exchange branch: the
+    collective after the pivot check, the winner's row in the record) and b7_nominate_commit (record row for model-based trials,
+    broadcast all-reduce for the random initial ones, offset shift).  RCCL refuses two ranks on one device, so its eight entry
+    points are served by a shared-memory test double loaded through B7_RCCL_LIB; every line of libbot7hip is the product's.
+    Every rank must reproduce the single-context run, the shards must concatenate to its candidate set, and a rank that fails
+    locally must make EVERY rank return B7_ERR_COMM (nobody hangs in the collective)."""
+    import json
+    import subprocess
+    from harness import dist
+    trials, grid = 7, _cfg1_grid()
+    ctx.grid_upload(grid)
+    one = dist.ShardedScorer(ctx, grid.shape[0], 0, 1)
+    xs1, ys1, best1 = _run_bot(one, ctx, trials, nSamples=3, sample=sample)
+    left1 = ctx.grid_download()
+    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), PYTHONPATH=ROOT, B7_TEST_SAMPLE="1" if sample else "0")
+    ident = ("b7stub_%d_%d" % (os.getpid(), world)).encode().hex()
+    outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_comm_worker.py"), str(r), str(world), ident, str(trials),
+                               outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append((p.returncode, e[-1500:]))
+    assert all(rc == 0 for rc, _ in logs), logs
+    res = [json.load(open(o)) for o in outs]
+    rows = []
+    for r, d in enumerate(res):
+        assert np.array_equal(np.array(d["nominees"]), xs1), "rank %d nominated differently" % r
+        assert np.array_equal(np.array(d["responses"]), ys1)
+        assert d["best"][0] == best1[0] and np.array_equal(np.array(d["best"][1]), best1[1]) and d["best"][2] == best1[2]
+        assert d["lo"] == sum(len(x["rows"]) for x in res[:r]), "rank %d: offset after %d commits" % (r, trials)
+        rows += d["rows"]
+        code = d["failure"][0] if isinstance(d["failure"], list) else None
+        assert code == (-1 if r == world - 1 else -7), "rank %d: %r" % (r, d["failure"])   # its own error / B7_ERR_COMM
+    assert np.array_equal(np.array(rows).reshape(-1, 2), left1)
