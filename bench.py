@@ -159,7 +159,9 @@ def main():
 
     import torch
     import torch.distributed as td
-    if not rccl:
+    if not rccl or os.environ.get("B7_RCCL_LIB"):
+        # ranks may share a GPU only in the rehearsals: the gloo exchange, or the tests' shared-memory double for RCCL's
+        # transport (tests/stub; the real RCCL refuses two ranks on one device)
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     grouped = "RANK" in os.environ  # launched by torch.distributed.run: join the group even when it has one rank

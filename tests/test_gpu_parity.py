@@ -944,6 +944,18 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(ctx):
     b2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert b2["n_gpus"] == 2 and b2["config"]["candidates_total"] == 131072 == b1["config"]["candidates_total"]
     assert b1["best"] == b2["best"], "sharded winner differs from the unsharded arg-max"
+    # the same two ranks through bench.py's PRODUCT path (--backend rccl: b7_comm_init + b7_eval_nominate's exchange branch),
+    # with RCCL's transport served by the shared-memory test double of tests/stub (RCCL refuses two ranks on one device)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from test_sharded_loop import _stub_lib
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--candidates", "65536"] + common,
+                           capture_output=True, text=True, env=dict(env, B7_RCCL_LIB=_stub_lib()), timeout=300)
+    assert three.returncode == 0, three.stderr[-2000:]
+    b3 = json.loads(three.stdout.strip().splitlines()[-1])
+    assert b3["n_gpus"] == 2 and "b7_eval_nominate" in b3["step_api"] and "ncclAllReduce" in b3["config"]["parallelism"]
+    assert b3["best"] == b1["best"], "winner through the communicator path differs from the unsharded arg-max"
 
 
 # ---- edge cases through the C ABI ---------------------------------------------------------------------------------
