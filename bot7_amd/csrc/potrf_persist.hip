@@ -286,10 +286,28 @@ struct Prefetch {
     d4_t u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
     const double *a0 = S1 + (16 * s0 + lr) * DLD + lq, *b0 = S1 + (16 * c0 + lr) * DLD + lq;
     const double *a1 = S1 + (16 * s1 + lr) * DLD + lq, *b1 = S1 + (16 * c1 + lr) * DLD + lq;
+    {
+      // the fragments of step k + 1 are requested between the MFMAs of step k (tools/mfma_feed_probe.hip: 94 -> 75 cycles per
+      // MFMA with one wave per SIMD); same products, same order
+      double f[2][4] = {{a0[0], b0[0], a1[0], b1[0]}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) {
-      u0 = mfma_f64(a0[4 * k4], b0[4 * k4], u0);
-      u1 = mfma_f64(a1[4 * k4], b1[4 * k4], u1);
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const int cur = k4 & 1, nxt = cur ^ 1;
+        u0 = mfma_f64(f[cur][0], f[cur][1], u0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 1 < 16) {
+          f[nxt][0] = a0[4 * (k4 + 1)];
+          f[nxt][1] = b0[4 * (k4 + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u1 = mfma_f64(f[cur][2], f[cur][3], u1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 1 < 16) {
+          f[nxt][2] = a1[4 * (k4 + 1)];
+          f[nxt][3] = b1[4 * (k4 + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -459,8 +477,18 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
     {
       d4_t u = {0.0, 0.0, 0.0, 0.0};
       const double *ar = S1 + (16 * wave + lr) * DLD + lq, *br = S1 + lr * DLD + lq;
+      double f[2][2] = {{ar[0], br[0]}, {0.0, 0.0}};
 #pragma unroll
-      for (int k4 = 0; k4 < 16; ++k4) u = mfma_f64(ar[4 * k4], br[4 * k4], u);
+      for (int k4 = 0; k4 < 16; ++k4) {  // the next step's two fragments requested behind this step's MFMA
+        const int cur = k4 & 1, nxt = cur ^ 1;
+        u = mfma_f64(f[cur][0], f[cur][1], u);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 1 < 16) {
+          f[nxt][0] = ar[4 * (k4 + 1)];
+          f[nxt][1] = br[4 * (k4 + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int e = (16 * wave + lq + 4 * rr) * DLD + lr;
