@@ -50,6 +50,9 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "b7oracle" not in src, f
+                # nor the test / bench harness (Python stand-ins for the reference's Lua host code) or the tests' RCCL double
+                assert not re.search(r"^\s*(from|import)\s+harness\b", src, re.M), f
+                assert "rccl_shm_stub" not in src, f
 
 
 def test_sobol_direction_numbers_match_oracle(orc):
