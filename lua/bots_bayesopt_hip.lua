@@ -68,7 +68,11 @@ function bot:nominate(candidates)
     keep[#keep + 1] = ls                                                     -- alive until the call has returned
     hyps[s-1].lenscale_sq, hyps[s-1].amp, hyps[s-1].noise, hyps[s-1].mean = hip.data(ls), hyp.amp, hyp.noise, hyp.mean
   end
-  model:stage(X_obs, Y_obs, candidates)                                      -- data + grid resident; uploads what changed
+  if candidates ~= nil then
+    model:stage(X_obs, Y_obs, candidates)                                    -- data + grid resident; uploads what changed
+  else
+    model:stage_data(X_obs, Y_obs)   -- this rank's shard has run empty: it still refits and takes part in the exchange
+  end
   local v, i = ffi.new('double[1]'), ffi.new('int64_t[1]')
   local jit, info = ffi.new('double[?]', S), ffi.new('int[?]', S)
   if hip.group then   -- one process, several GPUs: i indexes self.candidates, the host tensor of all candidates
