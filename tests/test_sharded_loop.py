@@ -447,3 +447,58 @@ def test_processes_sharing_the_gpu_run_the_trial_loop_through_the_communicator_p
         code = d["failure"][0] if isinstance(d["failure"], list) else None
         assert code == (-1 if r == world - 1 else -7), "rank %d: %r" % (r, d["failure"])   # its own error / B7_ERR_COMM
     assert np.array_equal(np.array(rows).reshape(-1, 2), left1)
+
+
+# ---- the boundary from plain C -----------------------------------------------------------------------------------------------
+def test_header_is_c99_and_cxx11():
+    """include/bot7hip.h is the drop-in boundary: it must compile as C (what cgo / LuaJIT's cdef / ctypes users assume) and as
+    C++, warning-free and pedantic."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "bot7hip.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+
+
+@pytest.mark.gpu
+def test_c_driver_runs_the_trial_loop_through_the_abi_alone(orc, tmp_path):
+    """examples/c_driver.c: a bot7 trial loop in C99 against the header and the .so, nothing else (grid from torch.rand's
+    stream, two random picks, GP + EI nominations, b7_nominate_commit).  Every model-based nomination must be the oracle's
+    arg-max on the data the driver had at that point, and the same loop over a single-process group of three virtual ranks
+    must print the same lines."""
+    import re
+    import subprocess
+    from bot7_amd import _lib
+    exe = str(tmp_path / "c_driver")
+    lib_dir = os.path.join(ROOT, "bot7_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_driver.c"), "-o", exe, "-L" + lib_dir, "-lbot7hip", "-lm",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    trials = 9
+    one = subprocess.run([exe, str(trials), "1"], capture_output=True, text=True, timeout=120)
+    assert one.returncode == 0, one.stderr
+    three = subprocess.run([exe, str(trials), "3"], capture_output=True, text=True, timeout=120)
+    assert three.returncode == 0, three.stderr
+    assert one.stdout == three.stdout, "the group of three virtual ranks printed a different run"
+    rows = re.findall(r"trial +(\d+) +idx +(\d+) +x = \(([^,]+), ([^)]+)\) +y = (\S+)", one.stdout)
+    assert len(rows) == trials
+    u = _lib.torch_rand(7, 256 * 2 + 2, 32)
+    cand = u[:512].reshape(256, 2).copy()
+    X, Y = [], []
+    for t, (tt, idx, x0, x1, y) in enumerate(rows, 1):
+        idx, x, y = int(idx), np.array([float(x0), float(x1)]), float(y)
+        if t <= 2:
+            assert idx == int(np.floor(u[512 + t - 1] * cand.shape[0])) + 1
+        else:
+            Xa, Ya = np.array(X), np.array(Y).reshape(-1, 1)
+            amp = float(np.var(Ya)) or 1.0
+            f = orc.gp.fit(Xa, Ya, np.full(2, 0.25), amp, 1e-4 * amp, float(np.mean(Ya)))
+            mu, var = orc.gp.predict(f, cand)
+            assert idx == orc.c.argmax_first(orc.c.ei(mu, var, [float(Ya.min())]))[0], "trial %d" % t
+        assert np.array_equal(x, cand[idx - 1])
+        from harness import benchmarks
+        assert y == pytest.approx(float(benchmarks.braninhoo(x)[0, 0]), rel=1e-13)
+        cand = np.delete(cand, idx - 1, axis=0)
+        X.append(x)
+        Y.append(y)
