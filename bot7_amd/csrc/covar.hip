@@ -210,10 +210,13 @@ __global__ void __launch_bounds__(256)
   constexpr int dpad = DPAD, NCH = (DPAD / 2 + TPR - 1) / TPR, KSTEPS = DPAD / 4;
   constexpr int stride = DPAD + 1;  // odd: conflict-free for the fused ds_read2_b64 fragment reads (gemm_f64.h)
   (void)dpad_rt;
-  constexpr int SQS = stride > 32 ? stride : 32;  // the query tile's rows double as the waves' store-staging strips
-  double *sq = sm;                          // KQ x SQS (rows of `stride` doubles in use)
-  double *so = sq + KQ * SQS;               // 2 x KO x stride
-  double *sh = so + 2 * KO * stride;        // 2 x KO   zs/2 of the slab
+  // The query tile is dead once its fragments sit in registers (before the first slab is consumed), so the two slab buffers
+  // live in the SAME LDS region: 50 -> 34 KB per workgroup at DPAD 32, 67 -> 34 at 64, 99 -> 50 at 96, i.e. three workgroups
+  // per CU (the register file's limit) instead of two at d = 64 and one at d = 96.  Costs two barriers in the prologue.
+  constexpr int R0 = (KQ * stride > 2 * KO * stride) ? KQ * stride : 2 * KO * stride;
+  double *sq = sm;                          // KQ x stride, prologue only
+  double *so = sm;                          // 2 x KO x stride, from the first slab on
+  double *sh = sm + R0;                     // 2 x KO   zs/2 of the slab
   double *sal = sh + 2 * KO;                // 2 x KO   alpha of the slab
   double *shq = sal + 2 * KO;               // KQ       xs/2 of the queries
   double *stab = shq + KQ;                  // 128      amp * 2^(j/128)
@@ -275,15 +278,16 @@ __global__ void __launch_bounds__(256)
     }
     shq[tid] = 0.5 * s;
   }
+  double qf[KSTEPS];  // this lane's A fragments: query row (wave*16 + lr), k = 4 k4 + lq
+#pragma unroll
+  for (int k4 = 0; k4 < KSTEPS; ++k4) qf[k4] = sq[(wave * 16 + lr) * stride + lq + 4 * k4];
+  __syncthreads();  // every wave holds its fragments, shq is complete: the region now belongs to the slabs
   store_slab(0);
   __syncthreads();
 
   double hq[4], macc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) hq[r] = shq[wave * 16 + lq + 4 * r];
-  double qf[KSTEPS];  // this lane's A fragments: query row (wave*16 + lr), k = 4 k4 + lq
-#pragma unroll
-  for (int k4 = 0; k4 < KSTEPS; ++k4) qf[k4] = sq[(wave * 16 + lr) * stride + lq + 4 * k4];
   // this lane's 16-byte store slots: even lanes write rows r = 0 and 2, odd lanes rows r = 1 and 3, two columns
   const bool odd = lane & 1;
   double *orow = out + ((int64_t)blockIdx.x * KQ + wave * 16 + lq + (odd ? 4 : 0)) * Npad + (lr & ~1);
@@ -324,26 +328,6 @@ __global__ void __launch_bounds__(256)
       for (int r = 0; r < 4; ++r) macc[r] = __builtin_fma(kv[r], al, macc[r]);
       // rows (lq, lq+4, lq+8, lq+12) x column lr  ->  16-byte stores of two adjacent columns: even lanes write rows r = 0
       // and 2 (their own value, then the odd neighbour's), odd lanes rows r = 1 and 3 (the even neighbour's, then their own)
-#if B7_KSX_ABLATE & 64
-      // Stores through an LDS transposition: the wave's strip of the query tile (dead since its fragments went to
-      // registers) takes two 16x16 tiles as [16][32] doubles, odd rows rotated by 16 columns (conflict-free writes); read
-      // back row-wise, one store instruction covers 4 rows x 256 contiguous bytes, and there is no lane-pair packing
-      {
-        double *tb = sq + wave * 16 * SQS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tb[(lq + 4 * r) * 32 + (((t & 1) * 16 + lr + 16 * (lq & 1)) & 31)] = kv[r];
-        if (t & 1) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = 4 * i + lq, col = lr * 2, cs = (col + 16 * (row & 1)) & 31;
-            d2_t v;
-            v[0] = tb[row * 32 + cs];
-            v[1] = tb[row * 32 + cs + 1];
-            *reinterpret_cast<d2_t *>(out + ((int64_t)blockIdx.x * KQ + wave * 16 + row) * Npad + o0 + (t - 1) * 16 + col) = v;
-          }
-        }
-      }
-#else
       d2_t v01, v23;
       pair_pack(kv[0], kv[1], v01);
       pair_pack(kv[2], kv[3], v23);
@@ -367,7 +351,6 @@ __global__ void __launch_bounds__(256)
         }
 #endif
       }
-#endif
     }
     if (more) store_slab(cur ^ 1);
     __syncthreads();
@@ -406,8 +389,13 @@ __global__ void __launch_bounds__(256)
 
 size_t ksx_lds_bytes(int dpad) {
   const int KO = ksx_slab(dpad);
-  const int sqs = dpad + 1 > 32 ? dpad + 1 : 32;
-  return sizeof(double) * ((size_t)KQ * sqs + (size_t)2 * KO * (dpad + 1) + 4 * KO + KQ + 128);
+  const size_t r0 = (size_t)(KQ > 2 * KO ? KQ : 2 * KO) * (dpad + 1);  // query tile and slab buffers share a region
+  size_t bytes = sizeof(double) * (r0 + 4 * KO + KQ + 128);
+#if B7_KSX_ABLATE & 128   // diagnostic: pad the request so that one workgroup fewer fits a CU (sensitivity to occupancy)
+  const size_t per_cu = 160 * 1024, fit = per_cu / bytes;
+  if (fit > 1) bytes = per_cu / (fit - 1) - 512;
+#endif
+  return bytes;
 }
 
 // the 2^(j/128) table goes to constant memory once per process and device

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = (0, 64)
+VARIANTS = (0, 128)
 
 
 def lib(v):
@@ -34,9 +34,9 @@ def build():
 
 
 def run(dims):
-    names = {0: "full", 1: "no stores", 2: "no table conflicts", 4: "no exp", 8: "one MFMA per tile", 16: "row-contiguous store addresses", 32: "non-temporal stores", 64: "stores through an LDS transposition"}
+    names = {0: "full", 1: "no stores", 2: "no table conflicts", 4: "no exp", 8: "one MFMA per tile", 16: "row-contiguous store addresses", 32: "non-temporal stores", 128: "one workgroup fewer per CU (LDS padded)"}
     for v in VARIANTS:
-        label = " + ".join(names[b] for b in (1, 2, 4, 8, 16, 32, 64) if v & b) or "full"
+        label = " + ".join(names[b] for b in (1, 2, 4, 8, 16, 32, 128) if v & b) or "full"
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ksx_rate.py")] + dims, capture_output=True, text=True,
                              env=dict(os.environ, BOT7HIP_LIB=lib(v)))
         print("== %s" % label)
