@@ -164,6 +164,7 @@ int b7_create(b7_ctx **out, int device_id) {
   c->persist_stamps = getenv("B7_PERSIST_STAMPS") != nullptr;
   if (const char *pv = getenv("B7_PERSIST_HELPERS")) c->persist_helpers = atoi(pv);
   if (const char *pv = getenv("B7_PERSIST_FAULT")) c->persist_fault = atoi(pv);
+  if (const char *pv = getenv("B7_NLL_SMALL")) c->nll_small = atoi(pv) != 0;  // 0: likelihoods of small sets through the general path too
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
@@ -210,6 +211,7 @@ void b7_destroy(b7_ctx *c) {
   resolve_phases(c);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pin_eval) (void)hipHostFree(c->pin_eval);
+  if (c->pin_nll) (void)hipHostFree(c->pin_nll);
   if (c->tab_host) (void)hipHostFree(c->tab_host);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
@@ -660,6 +662,44 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     if (!(amp[b] > 0.0) || !(noise[b] >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: amp > 0, noise >= 0 (fit %d)", b);
   }
   B7_HIP(c, hipSetDevice(c->device));
+  if (c->nll_small && nll_small_applies(c)) {
+    // N <= 128, d <= 32: every evaluation is ONE workgroup of ONE launch (nll_small.hip), observations in, two numbers out.
+    // A fit whose plain factorisation fails (rare) sends the whole batch through the general path below, jitter schedule
+    // included.
+    // hypers in and results out through ONE block of pinned, device-mapped host memory: the kernel reads the B x (d + 3)
+    // numbers and writes its 2 doubles + 4 ints per evaluation straight across the bus -- no copy calls, one launch, one wait
+    const size_t hyp_doubles = (size_t)B * (d + 3), need = sizeof(double) * (hyp_doubles + 2 * (size_t)B) + sizeof(int) * 4 * (size_t)B;
+    if (c->pin_nll_bytes < need) {
+      B7_HIP(c, hipStreamSynchronize(c->stream));
+      if (c->pin_nll) (void)hipHostFree(c->pin_nll);
+      c->pin_nll = nullptr;
+      c->pin_nll_bytes = 0;
+      B7_HIP(c, hipHostMalloc(&c->pin_nll, 2 * need, hipHostMallocMapped));
+      B7_HIP(c, hipHostGetDevicePointer(&c->pin_nll_dev, c->pin_nll, 0));
+      c->pin_nll_bytes = 2 * need;
+    }
+    double *pack = static_cast<double *>(c->pin_nll);
+    memcpy(pack, lenscale_sq, sizeof(double) * (size_t)B * d);
+    memcpy(pack + (size_t)B * d, amp, sizeof(double) * B);
+    memcpy(pack + (size_t)B * (d + 1), noise, sizeof(double) * B);
+    memcpy(pack + (size_t)B * (d + 2), mean, sizeof(double) * B);
+    const double *terms = pack + hyp_doubles;
+    const int *info = reinterpret_cast<const int *>(terms + 2 * (size_t)B);
+    double *pack_dev = static_cast<double *>(c->pin_nll_dev);
+    B7_TRY(launch_nll_small(c, B, pack_dev, pack_dev + hyp_doubles, reinterpret_cast<int *>(pack_dev + hyp_doubles + 2 * (size_t)B)));
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    bool clean = true;
+    for (int b = 0; b < B; ++b) clean = clean && info[(size_t)b * 4] == 0;
+    if (clean) {
+      const double c0s = 0.5 * N * log(2.0 * M_PI);
+      for (int b = 0; b < B; ++b) {
+        nll_out[b] = 0.5 * terms[(size_t)b * 2] + terms[(size_t)b * 2 + 1] + c0s;
+        if (jitter_out) jitter_out[b] = 0.0;
+        if (info_out) info_out[b] = 0;
+      }
+      return B7_OK;
+    }
+  }
   const size_t fw = persist_flag_words_host(nb), nn = (size_t)n * n;
   B7_TRY(b7_ensure(c, c->bhyp, sizeof(double) * (size_t)B * (d + 3)));
   B7_TRY(b7_ensure(c, c->bw, sizeof(double) * (size_t)B * dpad));

@@ -107,6 +107,8 @@ struct b7_ctx {
   void *pin_eval = nullptr;  // b7_eval_nominate: [S][4] pivot reports + [S][d] lengthscale staging (pinned)
   size_t pin_eval_bytes = 0;
   void *pinned_dev = nullptr;
+  void *pin_nll = nullptr, *pin_nll_dev = nullptr;  // b7_gp_nll_batch's small path: hypers in, results out (pinned, device-mapped)
+  size_t pin_nll_bytes = 0;
   bool fmin_staged = false;  // the fmin staging slot of the pinned block holds a caller's values
   bool potrf_attrs_set = false;  // dynamic-LDS limits of the Cholesky kernels raised (once per context)
   bool linv_done = false;  // launch_potrf produced Linv for the current factor
@@ -127,6 +129,7 @@ struct b7_ctx {
   bool persist_attr_set = false, persist_stamps = false;
   int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
+  bool nll_small = true;     // b7_gp_nll_batch at Npad <= 128, d <= 32: the one-workgroup-per-evaluation kernel (B7_NLL_SMALL)
   int persist_fault = -1;    // tests only (B7_PERSIST_FAULT): panel whose flag workgroup 0 withholds, to exercise the time-out
   int potrf_sched_saved = 0; // the schedule to return to after such a redo
   DevBuf part;   // argmax partials (value, index)
@@ -253,6 +256,9 @@ int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv,
 int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned *flags, int *info, const double *resid,
                    double *terms, double extra);
 size_t persist_flag_words_host(int nb);
+// nll_small.hip
+bool nll_small_applies(const b7_ctx *c);
+int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, double *terms_dev, int *info_dev);
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha);  // B single-column fits
 int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, unsigned *flags, int *info);

@@ -1,0 +1,248 @@
+// The GP likelihood for SMALL observation sets in one kernel, one workgroup per evaluation.
+//
+// Reference: model:sample_hypers (bots/bayesopt.lua:68,73-75) drives samplers/slice.lua:92-168, and every density evaluation
+// is K(X,X) + noise I (utils/math.lua:65-111), its Cholesky (utils/math.lua:159-218) and r' K^-1 r + log|K|.  With the
+// reference's own defaults (budget 100: bots/abstract.lua:64, so N <= 100) that is hundreds of SEQUENTIAL evaluations per
+// trial against one nomination, and at N <= 128 the general path (observation scaling, K assembly, fix-up, the persistent
+// factorisation with its vector job: six launches, each at the ~4.5 us dispatch floor, around 25 us of arithmetic) is bound by
+// launches, not by work.  Here a workgroup does all of it in LDS for one hyper vector: raw observations in, (|z|^2,
+// sum log L_ii, first bad pivot) out; B evaluations are B workgroups of one launch with no communication between them.
+//
+// The arithmetic is the general path's, operation for operation where that is cheap to say: K entries are the same
+// ascending fma chain over the input dimensions that a chain of v_mfma_f64_16x16x4 computes in ksx_kernel, the same
+// (c - xs/2) - zs/2 argument and the same table exponential (ksx_exp.h); the 64x64 diagonal blocks go through
+// b7diag::diag_core (potrf_diag.h), the block below by C inv(L11)' and the 64-deep update chain from zero followed by the
+// subtraction, as the persistent schedule does.  Only the final reductions (|z|^2, log-determinant) are summed in another
+// order; tests hold the result against the general path at 1e-12 relative.
+//
+// Limits: Npad <= 128 (one or two 64-blocks), d <= 32, one response column.  A failed pivot is reported, not repaired: the
+// caller redoes that evaluation through the general path and its jitter schedule.
+#include "b7_internal.h"
+#include "ksx_exp.h"
+#include "potrf_diag.h"
+
+namespace {
+using namespace b7diag;  // NB = 64, DLD, TLD, diag_core
+
+__constant__ double exp2_tab_small[128];  // B7_EXP2_TAB (ensure_small_table)
+
+constexpr int OLD = 33;  // row stride of the observation image [128][OLD] (32 columns, zero padded)
+constexpr int NLL_SMALL_LDS_DOUBLES = 128 * OLD + 3 * NB * DLD + 32 * TLD + 128 * 4 + 32 + 128 + 512;
+static_assert(128 * OLD <= NB * DLD, "the observation image is reused as the inverse's tile");
+
+// rows 0..15 x columns 48..63 of a block about to be factored: I_16 (potrf_diag.h: the right-hand side of the inversion)
+__device__ __forceinline__ void identity_corner(double *A) {
+  const int t = threadIdx.x;
+  if (t < 256) {
+    const int i = t >> 4, j = t & 15;
+    A[i * DLD + 48 + j] = (i == j) ? 1.0 : 0.0;
+  }
+}
+
+// one 64x64 tile of K(X,X) + noise I: entry (I0 + i, J0 + j) -> T[i][j]; rows / columns >= N are the identity
+__device__ __forceinline__ void k_tile(const double *__restrict__ obs, const double *__restrict__ w, const double *__restrict__ hn,
+                                       const double *__restrict__ tab, int I0, int J0, int N, double noise,
+                                       double *__restrict__ T) {
+  const int t = threadIdx.x, j = t & 63, i0 = t >> 6, gj = J0 + j;
+  double zj[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) zj[k] = obs[gj * OLD + k] * w[k];  // z .* w, rounded as prep_obs_kernel rounds it
+  const double hj = hn[gj];
+#pragma unroll 1
+  for (int e = 0; e < 16; e += 4) {
+    double arg[4], kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gi = I0 + i0 + 4 * (e + u);
+      const double *xi = obs + gi * OLD;
+      double c = 0.0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) c = __builtin_fma(xi[k], zj[k], c);
+      arg[u] = (c - hn[gi]) - hj;
+    }
+    amp_exp_nonpos4(arg, tab, kv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * (e + u), gi = I0 + i;
+      double v = kv[u];
+      if (gi >= N || gj >= N) v = (gi == gj) ? 1.0 : 0.0;
+      else if (gi == gj) v = v + noise;
+      T[i * DLD + j] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    nll_small_kernel(const double *__restrict__ xobs, const double *__restrict__ y, int N, int d, const double *__restrict__ hyp,
+                     int B, double *__restrict__ terms, int *__restrict__ info) {
+  extern __shared__ __align__(16) double sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int npad = N > 64 ? 128 : 64;
+  double *obs = sm;                    // [128][OLD], later X = inv(L_pp) [64][DLD]
+  double *X = sm;
+  double *A11 = sm + NB * DLD;         // [64][DLD]
+  double *A21 = A11 + NB * DLD;
+  double *A22 = A21 + NB * DLD;
+  double *T = A22 + NB * DLD;          // [32][TLD]
+  double *r = T + 32 * TLD;            // [128] residual, then z
+  double *hn = r + 128;                // [128] half norms
+  double *z = hn + 128;                // [128]
+  double *dg = z + 128;                // [128] diagonal of L
+  double *w = dg + 128;                // [32]
+  double *tab = w + 32;                // [128]
+  double *red = tab + 128;             // [512]
+  const double *ls = hyp + (size_t)b * d;
+  const double amp = hyp[(size_t)B * d + b], noise = hyp[(size_t)B * (d + 1) + b], mean = hyp[(size_t)B * (d + 2) + b];
+  int *inf = info + 4 * b;
+  if (tid < 4) inf[tid] = 0;
+  if (tid < 32) w[tid] = tid < d ? 1.0 / ls[tid] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
+  if (tid < 128) {
+    tab[tid] = amp * exp2_tab_small[tid];
+    r[tid] = tid < N ? y[tid] - mean : 0.0;
+  }
+  for (int e = tid; e < 128 * 32; e += 256) {
+    const int i = e >> 5, k = e & 31;
+    obs[i * OLD + k] = (i < N && k < d) ? xobs[(size_t)i * d + k] : 0.0;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    double s = 0.0;
+    for (int k = 0; k < 32; ++k) {
+      const double x = obs[tid * OLD + k];
+      s += (x * x) * w[k];  // Z_ss = (Z.^2) * inv_ls, :79 (the padding's half norm is never used: those entries are set)
+    }
+    hn[tid] = 0.5 * s;
+  }
+  __syncthreads();
+  k_tile(obs, w, hn, tab, 0, 0, N, noise, A11);
+  if (npad == 128) {
+    k_tile(obs, w, hn, tab, 64, 0, N, noise, A21);
+    k_tile(obs, w, hn, tab, 64, 64, N, noise, A22);
+  }
+  __syncthreads();  // the observation image is dead: its place becomes X
+  for (int e = tid; e < NB * DLD; e += 256) X[e] = 0.0;
+  identity_corner(A11);
+  __syncthreads();
+  diag_core<1, false>(A11, X, T, 0, inf, nullptr);  // A11 -> L11 (lower), X = inv(L11); ends with a barrier
+  // z1 = inv(L11) r1 (four lanes per row, ascending columns within each quarter, then the quarters in order)
+  {
+    const int row = tid >> 2, part = tid & 3;
+    double acc = 0.0;
+    for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(X[row * DLD + k], r[k], acc);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0) {
+      z[row] = acc;
+      dg[row] = A11[row * DLD + row];
+    }
+  }
+  __syncthreads();
+  if (npad == 128) {
+    // L21 = A21 inv(L11)': wave w rows 16 w .., four column blocks, k ascending, blocks above inv(L11)'s diagonal skipped
+    d4_t lv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    {
+      const double *ap = A21 + (wave * 16 + lr) * DLD + lq, *xp = X + lr * DLD + lq;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const double aq = ap[4 * t];
+#pragma unroll
+        for (int jb = t >> 2; jb < 4; ++jb) lv[jb] = mfma_f64(aq, xp[jb * 16 * DLD + 4 * t], lv[jb]);
+      }
+    }
+    __syncthreads();  // every wave is done reading A21
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) A21[(wave * 16 + lq + 4 * rr) * DLD + jb * 16 + lr] = lv[jb][rr];
+    __syncthreads();
+    // A22 -= L21 L21': per 16x16 sub-tile the 64-deep chain from zero, then the subtraction; r2 -= L21 z1
+    {
+      d4_t u[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      const double *ar = A21 + (16 * wave + lr) * DLD + lq;
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const double af = ar[4 * k4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) u[jb] = mfma_f64(af, A21[(16 * jb + lr) * DLD + lq + 4 * k4], u[jb]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          const int e = (16 * wave + lq + 4 * rr) * DLD + 16 * jb + lr;
+          A22[e] = A22[e] - u[jb][rr];
+        }
+      const int row = tid >> 2, part = tid & 3;
+      double acc = 0.0;
+      for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(A21[row * DLD + k], z[k], acc);
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (part == 0) r[64 + row] = r[64 + row] - acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * DLD; e += 256) X[e] = 0.0;
+    identity_corner(A22);
+    __syncthreads();
+    diag_core<1, false>(A22, X, T, 1, inf, nullptr);
+    {
+      const int row = tid >> 2, part = tid & 3;
+      double acc = 0.0;
+      for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(X[row * DLD + k], r[64 + k], acc);
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (part == 0) {
+        z[64 + row] = acc;
+        dg[64 + row] = A22[row * DLD + row];
+      }
+    }
+    __syncthreads();
+  }
+  // |z|^2 and sum log L_ii in a fixed order
+  double ssq = 0.0, ld = 0.0;
+  if (tid < npad) {
+    ssq = z[tid] * z[tid];
+    ld = log(dg[tid]);
+  }
+  red[tid] = ssq;
+  red[256 + tid] = ld;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[tid] += red[tid + o];
+      red[256 + tid] += red[256 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    terms[2 * b] = red[0];
+    terms[2 * b + 1] = red[256];
+  }
+}
+
+int ensure_small_table(b7_ctx *c) {
+  static bool done[64] = {false};
+  if (c->device < 64 && done[c->device]) return B7_OK;
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_small), B7_EXP2_TAB, sizeof(B7_EXP2_TAB)));
+  if (c->device < 64) done[c->device] = true;
+  return B7_OK;
+}
+
+}  // namespace
+
+bool nll_small_applies(const b7_ctx *c) { return c->Npad <= 128 && c->dfit <= 32 && c->ycols == 1; }
+
+// hyp_dev: [B x d lengthscales | B amp | B noise | B mean] (b7_gp_nll_batch's pack); terms_dev[2 B], info_dev[4 B]
+int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, double *terms_dev, int *info_dev) {
+  PhaseScope ps(c, "potrf");
+  B7_TRY(ensure_small_table(c));
+  const size_t lds = sizeof(double) * NLL_SMALL_LDS_DOUBLES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(nll_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(nll_small_kernel, dim3(B), dim3(256), lds, c->stream, (const double *)c->xobs.p, (const double *)c->ybuf.p, c->N,
+                     c->dfit, hyp_dev, B, terms_dev, info_dev);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}

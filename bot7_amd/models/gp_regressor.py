@@ -237,7 +237,19 @@ class gp_regressor(abstract):
         """Negative log marginal likelihood of (X_obs, Y_obs) under hyp: K + Cholesky + log-det + quadratic form
         on the device -- the unit of work behind the `GP-fit ms` metric."""
         hyp = hyp or self.hyp
-        out = self.ctx.gp_fit(X_obs, Y_obs, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+        X = np.atleast_2d(np.asarray(X_obs, dtype=np.float64))
+        Y = np.asarray(Y_obs, dtype=np.float64).reshape(X.shape[0], -1)
+        if Y.shape[1] == 1:
+            # the likelihood alone, of data that stay on the device across the sampler's evaluations: no inverse, no alpha,
+            # and for N <= 128 one workgroup of one launch (b7_gp_nll_batch)
+            key = self._data_key(X, Y)
+            if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
+                self.ctx.gp_set_data(X, Y)
+                self._resident_key = (key, self.ctx.fit_token)
+            nll, jit, info = self.ctx.gp_nll_batch(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_info=True)
+            self.last_fit = {"nll": nll, "jitter": float(jit[0]), "info": int(info[0])}
+            return nll
+        out = self.ctx.gp_fit(X, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
         self.last_fit = out
         return out["nll"]
 

@@ -158,9 +158,12 @@ int b7_gp_predict_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *mean_host, double 
 /* B likelihood evaluations of the resident data at once: the slice sampler's step-out / step-in probes
  * (samplers/slice.lua:118-164) and multi-chain samplers ask for the density at several hyper vectors per update.
  * lenscale_sq is B x d row-major; amp / noise / mean have B entries; nll_out[B] as b7_gp_fit_hyp's (same jitter schedule
- * per fit: jitter_out[B] / info_out[B], nullable).  The B factorisations run concurrently in ONE persistent launch (each
- * a chain of workgroups; 28 fit on the chip at N <= 256, 7 at N <= 512, larger ones go one after the other), with L z = r
- * solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched -- except
+ * per fit: jitter_out[B] / info_out[B], nullable).  N <= 128 observations with d <= 32 -- the reference's own regime
+ * (budget 100, bots/abstract.lua:64), where a trial is hundreds of sequential density evaluations against one nomination --
+ * take ONE workgroup of ONE launch per evaluation (observations in, two numbers out through device-mapped pinned memory: no
+ * copy calls; 50 us per call up to N = 64, 76 us up to 128, for 1 ... 256 evaluations alike).  Larger problems: the B
+ * factorisations run concurrently in ONE persistent launch (each a chain of workgroups; 28 fit on the chip at N <= 256, 7 at
+ * N <= 512, larger ones go one after the other), with L z = r solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched -- except
  * when a fit's hand-offs time out twice (the GPU is shared with another persistent kernel): that likelihood is then
  * evaluated through the launch schedule in the context's fit slot, and the next predict asks for a new fit (B7_ERR_STATE).
  * One response column, N <= 4096. */

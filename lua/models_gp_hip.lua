@@ -109,7 +109,15 @@ function model:fit(X_obs, Y_obs, hyp, want_nll)
   return nll[0]
 end
 
-function model:nll(X_obs, Y_obs, hyp) return self:fit(X_obs, Y_obs, hyp or self.hyp, true) end
+-- the likelihood alone (what the slice sampler evaluates, samplers/slice.lua:118-164): the data stay on the device, no inverse
+-- and no alpha are built, and for N <= 128 it is one workgroup of one launch (b7_gp_nll_batch with one hyper vector)
+function model:nll(X_obs, Y_obs, hyp)
+  local hyp = hyp or self.hyp
+  if (Y_obs:dim() == 2 and Y_obs:size(2) > 1) then return self:fit(X_obs, Y_obs, hyp, true) end
+  local h = hyp.lenscale_sq
+  local theta = torch.cat(h, torch.DoubleTensor{hyp.amp, hyp.noise, hyp.mean}):view(1, -1)
+  return self:nll_batch(X_obs, Y_obs, theta)[1]
+end
 
 -- B likelihoods at once (thetas: B x (d+3) rows in the hyper-vector layout above): one persistent launch for all of them,
 -- the current fit stays as it is.  For multi-chain samplers and speculative step-out probes.

@@ -1893,3 +1893,57 @@ def test_stage_keys_on_the_content_of_the_observations(ctx, orc):
         mu, var = orc.gp.predict(orc.gp.fit(X_obs, Yk, **hyp), X_hid)
         wi, wv = orc.c.argmax_first(orc.c.ei(mu, var, [float(Yk.min())]))
         assert i == wi, "stale observations were scored"
+
+
+# ---- the one-workgroup likelihood of small observation sets (csrc/nll_small.hip) ---------------------------------------
+def test_small_set_likelihood_kernel_equals_the_general_path_and_the_oracle(orc, monkeypatch):
+    """b7_gp_nll_batch at N <= 128, d <= 32 runs nll_small_kernel (one workgroup per evaluation, one launch); B7_NLL_SMALL=0
+    sends the same call through the general path (scaling, K assembly, persistent factorisation with its vector job).  Both
+    against the oracle and against each other (1e-12: same K entries, same factor routine, other summation order at the very
+    end) over ragged N (1 ... 128), d (1 ... 32), batch sizes 1 ... 300; a set that needs the jitter schedule (duplicated rows,
+    no noise) must fall back and report the same jitter; N = 129 and d = 33 take the general path on their own."""
+    import bot7_amd
+    monkeypatch.setenv("B7_NLL_SMALL", "0")
+    general = bot7_amd.Context(0)
+    monkeypatch.delenv("B7_NLL_SMALL")
+    small = bot7_amd.Context(0)
+    rng = np.random.default_rng(31)
+    for N, d, Bn in ((1, 1, 1), (2, 3, 4), (17, 2, 7), (63, 6, 16), (64, 32, 3), (65, 5, 16), (100, 6, 40), (127, 31, 2),
+                     (128, 32, 300), (129, 4, 5), (50, 33, 5)):
+        X = rng.random((N, d))
+        Y = np.sin(3.0 * X.sum(axis=1, keepdims=True)) + 0.05 * rng.normal(size=(N, 1))
+        ls = rng.random((Bn, d)) * d * 0.3 + 0.05 * d
+        amp = rng.random(Bn) + 0.5
+        noise = 10.0 ** rng.uniform(-5, -2, Bn)
+        mean = rng.normal(size=Bn) * 0.1
+        small.gp_set_data(X, Y)
+        general.gp_set_data(X, Y)
+        a, ja, ia = small.gp_nll_batch(ls, amp, noise, mean, want_info=True)
+        b, jb, ib = general.gp_nll_batch(ls, amp, noise, mean, want_info=True)
+        assert np.max(np.abs(a - b) / np.abs(b)) < 1e-12, (N, d)
+        assert np.array_equal(ja, jb) and np.array_equal(ia, ib)
+        for k in range(min(Bn, 4)):
+            want = float(orc.gp.fit(X, Y, ls[k], float(amp[k]), float(noise[k]), float(mean[k])).nll[0])
+            assert a[k] == pytest.approx(want, rel=1e-9, abs=1e-9), (N, d, k)
+        if N > 1:    # the single fit's likelihood is the same number too
+            one = small.gp_fit_hyp(ls[0], float(amp[0]), float(noise[0]), float(mean[0]), want_nll=True)
+            assert a[0] == pytest.approx(float(one["nll"][0]), rel=1e-12)
+    # a failing plain attempt: duplicated observations without noise
+    X = rng.random((40, 3))
+    X = np.concatenate([X, X[:5]])
+    Y = np.cos(X.sum(axis=1, keepdims=True))
+    ls = np.full((3, 3), 0.4)
+    for c in (small, general):
+        c.gp_set_data(X, Y)
+    a, ja, ia = small.gp_nll_batch(ls, 1.0, 0.0, 0.0, want_info=True)
+    b, jb, ib = general.gp_nll_batch(ls, 1.0, 0.0, 0.0, want_info=True)
+    assert (ja > 0).all() and np.array_equal(ja, jb) and np.array_equal(ia, ib) and np.array_equal(a, b)
+    # the sampler's density goes through it: model.nll keeps the data resident and evaluates the likelihood alone
+    model = bot7_amd.models.gp_regressor({}, context=small)
+    Xs, Ys = rng.random((30, 4)), rng.normal(size=(30, 1))
+    h = {"lenscale_sq": np.full(4, 0.7), "amp": 1.3, "noise": 1e-3, "mean": 0.2}
+    v1 = float(model.nll(Xs, Ys, h)[0])
+    assert v1 == pytest.approx(float(orc.gp.fit(Xs, Ys, **h).nll[0]), rel=1e-9)
+    assert float(model.nll(Xs, -Ys, h)[0]) != v1     # new data of the same shape are noticed (content key)
+    small.close()
+    general.close()
