@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "b7_internal.h"
+#include <chrono>
 
 static thread_local std::string g_create_err;
 
@@ -668,7 +669,7 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     // included.
     // hypers in and results out through ONE block of pinned, device-mapped host memory: the kernel reads the B x (d + 3)
     // numbers and writes its 2 doubles + 4 ints per evaluation straight across the bus -- no copy calls, one launch, one wait
-    const size_t hyp_doubles = (size_t)B * (d + 3), need = sizeof(double) * (hyp_doubles + 2 * (size_t)B) + sizeof(int) * 4 * (size_t)B;
+    const size_t hyp_doubles = (size_t)B * (d + 3), need = sizeof(double) * (hyp_doubles + 2 * (size_t)B) + sizeof(int) * (4 * (size_t)B + 4);
     if (c->pin_nll_bytes < need) {
       B7_HIP(c, hipStreamSynchronize(c->stream));
       if (c->pin_nll) (void)hipHostFree(c->pin_nll);
@@ -686,8 +687,23 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     const double *terms = pack + hyp_doubles;
     const int *info = reinterpret_cast<const int *>(terms + 2 * (size_t)B);
     double *pack_dev = static_cast<double *>(c->pin_nll_dev);
-    B7_TRY(launch_nll_small(c, B, pack_dev, pack_dev + hyp_doubles, reinterpret_cast<int *>(pack_dev + hyp_doubles + 2 * (size_t)B)));
-    B7_HIP(c, hipStreamSynchronize(c->stream));
+    int *info_dev = reinterpret_cast<int *>(pack_dev + hyp_doubles + 2 * (size_t)B);
+    // a single evaluation (every density call of the slice sampler) is waited for on a word the kernel sets after its results:
+    // the host sees them as soon as they have crossed the bus instead of after the dispatch has retired and the runtime
+    // has noticed.  The stream stays ordered (later launches queue behind the kernel); a kernel that has not answered after
+    // 200 us is waited for the ordinary way, which also surfaces a fault.
+    volatile unsigned *done = reinterpret_cast<volatile unsigned *>(const_cast<int *>(info) + 4 * (size_t)B);
+    *done = 0u;
+    B7_TRY(launch_nll_small(c, B, pack_dev, pack, pack_dev + hyp_doubles, info_dev, reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B)));
+    bool answered = false;
+    if (B == 1) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0; !answered; ++spins) {
+        answered = __atomic_load_n(const_cast<const unsigned *>(done), __ATOMIC_ACQUIRE) != 0u;
+        if (!answered && (spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+      }
+    }
+    if (!answered) B7_HIP(c, hipStreamSynchronize(c->stream));
     bool clean = true;
     for (int b = 0; b < B; ++b) clean = clean && info[(size_t)b * 4] == 0;
     if (clean) {

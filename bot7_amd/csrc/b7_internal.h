@@ -258,7 +258,8 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
 size_t persist_flag_words_host(int nb);
 // nll_small.hip
 bool nll_small_applies(const b7_ctx *c);
-int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, double *terms_dev, int *info_dev);
+int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
+                     unsigned *done_dev);
 int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
 int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha);  // B single-column fits
 int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, unsigned *flags, int *info);

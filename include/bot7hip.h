@@ -161,7 +161,8 @@ int b7_gp_predict_hyp(b7_ctx *ctx, const b7_hyp *hyp, double *mean_host, double 
  * per fit: jitter_out[B] / info_out[B], nullable).  N <= 128 observations with d <= 32 -- the reference's own regime
  * (budget 100, bots/abstract.lua:64), where a trial is hundreds of sequential density evaluations against one nomination --
  * take ONE workgroup of ONE launch per evaluation (observations in, two numbers out through device-mapped pinned memory: no
- * copy calls; 50 us per call up to N = 64, 76 us up to 128, for 1 ... 256 evaluations alike).  Larger problems: the B
+ * copy calls; B = 1 carries its hypers in the kernel arguments and waits on a completion word instead of the stream:
+ * 24 us per call up to N = 64, 43 us up to 128; a batch of up to 256 costs ~7 us more).  Larger problems: the B
  * factorisations run concurrently in ONE persistent launch (each a chain of workgroups; 28 fit on the chip at N <= 256, 7 at
  * N <= 512, larger ones go one after the other), with L z = r solved alongside: no inverse, no alpha.  The context's current fit (and its predictions) is left untouched -- except
  * when a fit's hand-offs time out twice (the GPU is shared with another persistent kernel): that likelihood is then

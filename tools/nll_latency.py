@@ -7,6 +7,7 @@ import time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bot7_amd  # noqa: E402
+from bot7_amd import _lib  # noqa: E402
 from harness import benchmarks  # noqa: E402
 from oracle import gp  # noqa: E402
 
@@ -34,5 +35,15 @@ for d, N, fn in ((2, 24, benchmarks.braninhoo), (6, 64, benchmarks.hartmann6), (
                 c.gp_nll_batch(ls[:B], amp, 1e-4 * amp, float(np.mean(Y)))
             t = (time.perf_counter() - t0) / 200
             line += "  %s B=%2d %.1f us" % ("small" if flag == "1" else "general", B, t * 1e6)
+            if B == 1:
+                # the C call alone (what a Lua / C host pays): arguments converted once, ctypes' own call cost (~1 us) included
+                L = _lib.load()
+                a = [np.ascontiguousarray(v, dtype=np.float64) for v in (ls[:1], [amp], [1e-4 * amp], [float(np.mean(Y))])]
+                out = np.empty(1)
+                args = [c._h, 1] + [_lib._ptr(v) for v in a] + [_lib._ptr(out), None, None]
+                t0 = time.perf_counter()
+                for _ in range(500):
+                    L.b7_gp_nll_batch(*args)
+                line += " (C call %.1f us)" % ((time.perf_counter() - t0) / 500 * 1e6)
         line += " (rel err vs oracle %.1e)" % err
     print(line, flush=True)
