@@ -201,7 +201,12 @@ __global__ void __launch_bounds__(256)
   identity_corner(A11);
   __syncthreads();
   STAMP();  // 5
+#ifdef B7_NLL_STAMP
+  __shared__ unsigned long long dst_[24];  // the factor routine's own phase stamps (slots 2..17), first block
+  diag_core<1, true>(A11, X, T, 0, inf, dst_);
+#else
   diag_core<1, false>(A11, X, T, 0, inf, nullptr);  // A11 -> L11 (lower), X = inv(L11); ends with a barrier
+#endif
   STAMP();  // 6
   // z1 = inv(L11) r1 (four lanes per row, ascending columns within each quarter, then the quarters in order)
   {
@@ -300,7 +305,8 @@ __global__ void __launch_bounds__(256)
   STAMP();  // last
   if (tid == 0) {
 #ifdef B7_NLL_STAMP
-    terms[2 * b] = b < sn_ ? (double)(st_[b] - st_[0]) : -1.0;   // workgroup b reports stamp b (experiment build only)
+    // workgroup b reports stamp b; workgroups 16.. the factor routine's slots 2.. relative to its entry (experiment build only)
+    terms[2 * b] = b < 16 ? (b < sn_ ? (double)(st_[b] - st_[0]) : -1.0) : (b < 32 ? (double)(dst_[b - 14] - st_[5]) : -1.0);
     terms[2 * b + 1] = 0.0;
 #else
     terms[2 * b] = (red[0] + red[1]) + (red[2] + red[3]);

@@ -42,6 +42,16 @@ __device__ __forceinline__ double row_share64(double v) {
 // states after a VALU write of the same register and the compiler cannot see into asm: the statements are volatile
 // (kept in program order) and every caller keeps at least two other instructions between the write of `src` and
 // this read (see the 16x16 routine; s_nop 1 would cost 8 cycles each).
+// The same broadcast for a value that an asm statement wrote (the pivot chain): straight from that register into a fresh
+// one.  The builtin ties source and destination, so the compiler copies the value first and pads copy -> DPP with its own
+// wait states (three issue slots per column); here the two wait states after the asm write are the caller's business, as
+// for fmac_share.
+template <int J>
+__device__ __forceinline__ double row_share64_raw(double v) {
+  double out;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "n"(J));
+  return out;
+}
 template <int J>
 __device__ __forceinline__ void fmac_share(double &acc, double src, double mul) {
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
@@ -84,6 +94,29 @@ __device__ __forceinline__ void block16_update(double *__restrict__ A, int i, in
 }
 
 
+// The dependent chain that opens column J of the 16x16 factor step, one link per call so that the caller can place the
+// links between the previous column's multiply-adds (diag_core): broadcast the pivot, its reciprocal by estimate and two
+// Newton steps, the multiplier -c_iJ r_J, s_J = rhs_J - sum and its scaled copy, the pivot kept for the failure test.
+template <int VAR>
+struct PivotChain {
+  static constexpr int LINKS = 10;
+  double dj, r, e, nm, xs;
+  template <int I, int J>
+  __device__ __forceinline__ void link(double (&a)[16], double (&x)[16], const double (&rhs)[16], const double (&sacc)[16],
+                                       double &dmine, int lr) {
+    if constexpr (I == 0) dj = (VAR == 2) ? row_share64<J>(a[J]) : row_share64_raw<J>(a[J]);
+    if constexpr (I == 1) r = __builtin_amdgcn_rcp(dj);
+    if constexpr (I == 2) x[J] = rhs[J] - sacc[J];  // independent of the reciprocal: fills its latency
+    if constexpr (I == 3) e = __builtin_fma(-dj, r, 1.0);
+    if constexpr (I == 4) r = __builtin_fma(e, r, r);
+    if constexpr (I == 5) e = __builtin_fma(-dj, r, 1.0);
+    if constexpr (I == 6) r = __builtin_fma(e, r, r);
+    if constexpr (I == 7) nm = -(a[J] * r);  // -l~_iJ of the LDL' form (rows i > J)
+    if constexpr (I == 8) xs = x[J] * r;
+    if constexpr (I == 9) dmine = (lr == J) ? dj : dmine;
+  }
+};
+
 // A: [64][DLD] the block (lower part meaningful; VAR 1 expects I_16 in rows 0..15 x columns 48..63), X: [64][DLD]
 // zero on entry, T: [32][TLD] scratch.  On return (after the closing barrier) A's lower triangle is L_pp and X is
 // inv(L_pp) (zero above the diagonal).  A non-positive / NaN / subnormal pivot is reported dpotrf-style through
@@ -122,7 +155,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       // with the identity as right-hand side.  The four 16-lane rows of the wave replicate the factorisation
       // anyway (DPP broadcasts stay inside a row), so rows 1..3 run the SAME instructions on a different right-hand
       // side: one row each of the sub-panel blocks below, which come out solved (L_ik = A_ik inv(L_kk)') for free.
-      double a[16], x[16], xs[16], rhs[16];
+      double a[16], x[16], rhs[16], sacc[16];
       const int ib = kb + lq;  // sub-panel block of this lane row (lq >= 1); lane row 0 carries the inverse
       const bool has_sub = lq > 0 && ib < 4;
       // every lane reads its right-hand side through one pointer, no selects: the identity rows live in the
@@ -133,28 +166,45 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       for (int k = 0; k < 16; ++k) {
         a[k] = A[(o + lr) * DLD + o + k];
         rhs[k] = rsrc[k];
+        sacc[k] = 0.0;
       }
       double dmine = 1.0;
+      // The substitution is RIGHT-looking: as soon as s_j is known its contribution c_mj (r_j s_j) goes to the sums of all
+      // later rows m, one independent multiply-add each, instead of row j collecting its j terms in one dependent chain when
+      // its turn comes.  Every sum still receives its terms in ascending k from zero -- the bits are those of the left-looking
+      // form -- but nothing in a column now waits on anything except the pivot chain itself (d_j, its reciprocal, the
+      // multiplier, s_j: ten dependent operations, ~10 cycles of latency each against ~5 of issue), and that chain is
+      // software-pipelined by hand into the PREVIOUS column's multiply-adds: the first pair of a column finishes what the
+      // next column's chain needs (c_j+1,j+1 and the sum of row j + 1), the other 2 (14 - j) are independent of it and
+      // one link of the chain goes between every two (from column 5 on: every one) of them.  sched_barrier pins that order;
+      // the measured cost of a 16-column step fell from 4400 to the cycles tools/nll_small_stamps.py reports.
+      PivotChain<VAR> pc;
+      static_for<PivotChain<VAR>::LINKS>([&](auto Ic) { pc.template link<decltype(Ic)::value, 0>(a, x, rhs, sacc, dmine, lr); });
       static_for<16>([&](auto Jc) {
-        constexpr int j = Jc;
-        const double dj = row_share64<j>(a[j]);
-        dmine = (lr == j) ? dj : dmine;
-        double r = __builtin_amdgcn_rcp(dj);
-        r = __builtin_fma(__builtin_fma(-dj, r, 1.0), r, r);
-        r = __builtin_fma(__builtin_fma(-dj, r, 1.0), r, r);
-        const double nm = -(a[j] * r);  // -l~_ij of the LDL' form (rows i > j)
-        static_for<16>([&](auto Kc) {
-          constexpr int k = Kc;
-          if constexpr (k > j) fmac_bcast<VAR, k>(a[k], a[j], nm);  // c_ik -= l~_ij c_kj; a[j] was last written >= 2 asm ago
+        constexpr int j = Jc, R = 15 - j;            // R columns k > j
+        constexpr int STRIDE = (2 * (R - 2) >= 2 * PivotChain<VAR>::LINKS) ? 2 : 1;  // multiply-adds between two links of the chain
+        const double nm = pc.nm, xsj = pc.xs;         // this column's multipliers: the chain below overwrites pc
+        static_for<2 * (R > 0 ? R : 0)>([&](auto Fc) {
+          constexpr int f = Fc, k = j + 1 + f / 2;
+          if constexpr (f % 2 == 0)
+            fmac_bcast<VAR, k>(a[k], a[j], nm);      // c_ik -= l~_ij c_kj; a[j] was last written >= 2 asm ago
+          else
+            fmac_bcast<VAR, k>(sacc[k], a[j], xsj);  // sum of row k += c_kj (r_j s_j)
+          // links of column j + 1's chain: after the second pair (c_j+1,j+1 was written by the first multiply-add of
+          // this list and is read through DPP: two wait states, kept here by the three asm statements in between)
+          if constexpr (f >= 3 && (f - 3) % STRIDE == 0 && (f - 3) / STRIDE < PivotChain<VAR>::LINKS) {
+            __builtin_amdgcn_sched_barrier(0);
+            pc.template link<(f - 3) / STRIDE, j + 1>(a, x, rhs, sacc, dmine, lr);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         });
-        // row j of the unit-lower inverse, lane lr holding column lr: x~_j = [j == lr] - sum_{k<j} c_jk (r_k x~_k)
-        double sacc = 0.0;
-        static_for<16>([&](auto Kc) {
-          constexpr int k = Kc;
-          if constexpr (k < j) fmac_bcast<VAR, j>(sacc, a[k], xs[k]);
-        });
-        x[j] = rhs[j] - sacc;
-        xs[j] = x[j] * r;
+        if constexpr (j < 15) {
+          // what is left of the chain once the multiply-adds have run out (late columns: the block's serial tail)
+          constexpr int done = (2 * R >= 4) ? ((2 * R - 4) / STRIDE + 1 < PivotChain<VAR>::LINKS ? (2 * R - 4) / STRIDE + 1 : PivotChain<VAR>::LINKS) : 0;
+          if constexpr (2 * R < 4) asm volatile("s_nop 1");  // column 14: only one asm statement follows the write of c_15,15
+          static_for<PivotChain<VAR>::LINKS - done>(
+              [&](auto Ic) { pc.template link<done + decltype(Ic)::value, j + 1>(a, x, rhs, sacc, dmine, lr); });
+        }
       });
       // also NaN, like dpotrf's test; a subnormal pivot counts as failed too (its reciprocal overflows)
       const unsigned long long badmask = __ballot(!(dmine >= 2.2250738585072014e-308)) & 0xFFFFull;
@@ -163,9 +213,10 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       const double hp = 0.5 * dmine;
       ymine = ymine * __builtin_fma(-hp * ymine, ymine, 1.5);
       ymine = ymine * __builtin_fma(-hp * ymine, ymine, 1.5);
+      if constexpr (VAR != 2) asm volatile("s_nop 1" : "+v"(ymine));  // two wait states between the VALU write and the DPP reads
       static_for<16>([&](auto Kc) {
         constexpr int k = Kc;
-        const double yk = row_share64<k>(ymine);
+        const double yk = (VAR == 2) ? row_share64<k>(ymine) : row_share64_raw<k>(ymine);
         a[k] *= yk;  // L[lr][k] = c_lr,k / sqrt(d_k)
         x[k] *= yk;  // lane row 0: inv(L)[k][lr] = s_k / sqrt(d_k); lane rows 1..3: L_ik[lr][k]
       });

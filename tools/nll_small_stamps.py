@@ -42,16 +42,24 @@ def run():
         X = rng.random((N, d))
         Y = rng.normal(size=(N, 1))
         ctx.gp_set_data(X, Y)
-        B = 16
+        B = 32
         for _ in range(3):
             nll = ctx.gp_nll_batch(np.full((B, d), 0.3), 1.0, 1e-3, 0.0)
         st = 2.0 * (np.asarray(nll) - 0.5 * N * math.log(2 * math.pi))
-        st = [s for s in st if s >= 0]
+        diag = list(st[16:32])
+        st = [s for s in st[:16] if s >= 0]
         names = NAMES if N > 64 else NAMES[:8] + NAMES[-1:]
         st = st[:len(names)]
         print("d %d N %d: total %.0f cycles" % (d, N, st[-1]))
         for k in range(1, len(st)):
             print("   %-40s %7.0f cycles" % (names[k] if k < len(names) else "?", st[k] - st[k - 1]))
+        # the factor routine's first call, per 16-column step: wave 0's pivot chain | barrier | (VAR 0's sub-panel) | update + barrier
+        prev = 0.0
+        for kb in range(4):
+            f, b_, s_, u = diag[4 * kb:4 * kb + 4]
+            print("   diag_core step %d: chain %6.0f  barrier %5.0f  update + barrier %6.0f   (cycles)" % (kb, f - prev, b_ - f, u - b_))
+            prev = u
+        print("   diag_core tail (rest of the inverse doubling): %.0f cycles" % (st[6] - st[5] - prev))
 
 
 if __name__ == "__main__":
