@@ -663,27 +663,28 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     if (!(amp[b] > 0.0) || !(noise[b] >= 0.0)) return b7_fail(c, B7_ERR_INVALID, "gp_nll_batch: amp > 0, noise >= 0 (fit %d)", b);
   }
   B7_HIP(c, hipSetDevice(c->device));
+  // hypers in and results out through ONE block of pinned, device-mapped host memory, laid out
+  // [B x d lengthscales | B amp | B noise | B mean][2 B terms][4 B ints of pivot reports][completion word]
+  const size_t hyp_doubles = (size_t)B * (d + 3), need = sizeof(double) * (hyp_doubles + 2 * (size_t)B) + sizeof(int) * (4 * (size_t)B + 4);
+  if (c->pin_nll_bytes < need) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->pin_nll) (void)hipHostFree(c->pin_nll);
+    c->pin_nll = nullptr;
+    c->pin_nll_bytes = 0;
+    B7_HIP(c, hipHostMalloc(&c->pin_nll, 2 * need, hipHostMallocMapped));
+    B7_HIP(c, hipHostGetDevicePointer(&c->pin_nll_dev, c->pin_nll, 0));
+    c->pin_nll_bytes = 2 * need;
+  }
+  double *pack = static_cast<double *>(c->pin_nll);
+  memcpy(pack, lenscale_sq, sizeof(double) * (size_t)B * d);
+  memcpy(pack + (size_t)B * d, amp, sizeof(double) * B);
+  memcpy(pack + (size_t)B * (d + 1), noise, sizeof(double) * B);
+  memcpy(pack + (size_t)B * (d + 2), mean, sizeof(double) * B);
   if (c->nll_small && nll_small_applies(c)) {
     // N <= 128, d <= 32: every evaluation is ONE workgroup of ONE launch (nll_small.hip), observations in, two numbers out.
     // A fit whose plain factorisation fails (rare) sends the whole batch through the general path below, jitter schedule
-    // included.
-    // hypers in and results out through ONE block of pinned, device-mapped host memory: the kernel reads the B x (d + 3)
-    // numbers and writes its 2 doubles + 4 ints per evaluation straight across the bus -- no copy calls, one launch, one wait
-    const size_t hyp_doubles = (size_t)B * (d + 3), need = sizeof(double) * (hyp_doubles + 2 * (size_t)B) + sizeof(int) * (4 * (size_t)B + 4);
-    if (c->pin_nll_bytes < need) {
-      B7_HIP(c, hipStreamSynchronize(c->stream));
-      if (c->pin_nll) (void)hipHostFree(c->pin_nll);
-      c->pin_nll = nullptr;
-      c->pin_nll_bytes = 0;
-      B7_HIP(c, hipHostMalloc(&c->pin_nll, 2 * need, hipHostMallocMapped));
-      B7_HIP(c, hipHostGetDevicePointer(&c->pin_nll_dev, c->pin_nll, 0));
-      c->pin_nll_bytes = 2 * need;
-    }
-    double *pack = static_cast<double *>(c->pin_nll);
-    memcpy(pack, lenscale_sq, sizeof(double) * (size_t)B * d);
-    memcpy(pack + (size_t)B * d, amp, sizeof(double) * B);
-    memcpy(pack + (size_t)B * (d + 1), noise, sizeof(double) * B);
-    memcpy(pack + (size_t)B * (d + 2), mean, sizeof(double) * B);
+    // included.  The kernel reads the B x (d + 3) numbers and writes its 2 doubles + 4 ints per evaluation straight across
+    // the bus -- no copy calls, one launch, one wait
     const double *terms = pack + hyp_doubles;
     const int *info = reinterpret_cast<const int *>(terms + 2 * (size_t)B);
     double *pack_dev = static_cast<double *>(c->pin_nll_dev);
@@ -724,30 +725,31 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
   B7_TRY(b7_ensure(c, c->bK, sizeof(double) * B * nn));
   B7_TRY(b7_ensure(c, c->bL, sizeof(double) * B * nn));
   B7_TRY(b7_ensure(c, c->bdinv, sizeof(double) * (size_t)B * n * B7_PANEL));
-  B7_TRY(b7_ensure(c, c->bflags, sizeof(unsigned) * B * fw));
-  B7_TRY(b7_ensure(c, c->binfo, sizeof(int) * 4 * (size_t)B));
+  // one block: [2 B doubles of likelihood terms][4 B ints of pivot reports][B x fw flag words] -- reports and flags are zeroed
+  // by one memset, terms and reports come back in one copy; the jitter schedule's norm goes into bterms
+  const size_t head_bytes = sizeof(double) * 2 * (size_t)B + sizeof(int) * 4 * (size_t)B;
+  B7_TRY(b7_ensure(c, c->bflags, head_bytes + sizeof(unsigned) * B * fw));
   B7_TRY(b7_ensure(c, c->bresid, sizeof(double) * (size_t)B * n));
-  B7_TRY(b7_ensure(c, c->bterms, sizeof(double) * 2 * (size_t)B + 64));
-  // all hypers in one upload: [B x d lengthscales | B amp | B noise | B mean]
-  std::vector<double> pack((size_t)B * (d + 3));
-  memcpy(pack.data(), lenscale_sq, sizeof(double) * (size_t)B * d);
-  memcpy(pack.data() + (size_t)B * d, amp, sizeof(double) * B);
-  memcpy(pack.data() + (size_t)B * (d + 1), noise, sizeof(double) * B);
-  memcpy(pack.data() + (size_t)B * (d + 2), mean, sizeof(double) * B);
+  B7_TRY(b7_ensure(c, c->bterms, 64));
+  // all hypers in one upload from the pinned block (no pageable staging)
   double *hyp_dev = (double *)c->bhyp.p;
-  B7_HIP(c, hipMemcpyAsync(hyp_dev, pack.data(), sizeof(double) * pack.size(), hipMemcpyHostToDevice, c->stream));
+  B7_HIP(c, hipMemcpyAsync(hyp_dev, pack, sizeof(double) * hyp_doubles, hipMemcpyHostToDevice, c->stream));
   const double *ls_dev = hyp_dev, *amp_dev = hyp_dev + (size_t)B * d, *noise_dev = amp_dev + B, *mean_dev = noise_dev + B;
   hipLaunchKernelGGL(resid_batch_kernel, dim3((n + 255) / 256, B), dim3(256), 0, c->stream, (const double *)c->ybuf.p,
                      (double *)c->bresid.p, N, n, mean_dev);
   B7_TRY(launch_kxx_batch(c, B, ls_dev, amp_dev, noise_dev, (double *)c->bw.p, (double *)c->bzsc.p, (double *)c->bzss.p,
                           (double *)c->bK.p));
-  B7_TRY(launch_nll_batch(c, B, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bdinv.p, (unsigned *)c->bflags.p,
-                          (int *)c->binfo.p, (const double *)c->bresid.p, (double *)c->bterms.p, nullptr));
-  std::vector<int> info((size_t)B * 4);
-  std::vector<double> terms((size_t)B * 2);
-  B7_HIP(c, hipMemcpyAsync(info.data(), c->binfo.p, sizeof(int) * info.size(), hipMemcpyDeviceToHost, c->stream));
-  B7_HIP(c, hipMemcpyAsync(terms.data(), c->bterms.p, sizeof(double) * terms.size(), hipMemcpyDeviceToHost, c->stream));
-  B7_HIP(c, hipStreamSynchronize(c->stream));  // also: `pack` has been consumed
+  // the likelihood terms and the pivot reports of all fits sit side by side on the device ([2 B doubles][4 B ints]) and come
+  // back in ONE copy into the pinned block
+  double *terms_dev = (double *)c->bflags.p;
+  int *info_dev = reinterpret_cast<int *>(terms_dev + 2 * (size_t)B);
+  unsigned *flags_dev = reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B);
+  B7_TRY(launch_nll_batch(c, B, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bdinv.p, flags_dev,
+                          info_dev, (const double *)c->bresid.p, terms_dev, nullptr));
+  double *terms = pack + hyp_doubles;
+  int *info = reinterpret_cast<int *>(terms + 2 * (size_t)B);
+  B7_HIP(c, hipMemcpyAsync(terms, terms_dev, sizeof(double) * 2 * (size_t)B + sizeof(int) * 4 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
   const double c0 = 0.5 * N * log(2.0 * M_PI);
   for (int b = 0; b < B; ++b) {
     double jitter = 0.0;
@@ -755,10 +757,10 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     int bad = info_first, aborted = info[(size_t)b * 4 + 1];
     const double *Kb = (const double *)c->bK.p + b * nn;
     double *Lb = (double *)c->bL.p + b * nn, *dib = (double *)c->bdinv.p + (size_t)b * n * B7_PANEL;
-    unsigned *fb = (unsigned *)c->bflags.p + b * fw;
-    int *ib = (int *)c->binfo.p + (size_t)b * 4;
+    unsigned *fb = flags_dev + b * fw;
+    int *ib = info_dev + (size_t)b * 4;
     const double *rb = (const double *)c->bresid.p + (size_t)b * n;
-    double *tb = (double *)c->bterms.p + 2 * (size_t)b;
+    double *tb = terms_dev + 2 * (size_t)b;
     auto redo = [&](double extra) -> int {  // this fit alone (it has the whole chip), eps on the diagonal
       B7_TRY(launch_nll_one(c, Kb, Lb, dib, fb, ib, rb, tb, extra));
       int two[2];
@@ -792,7 +794,7 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
       continue;
     }
     if (bad != 0) {  // the jitter schedule of utils/math.lua:174-202 for this fit
-      double *fro_dev = (double *)c->bterms.p + 2 * (size_t)B;
+      double *fro_dev = (double *)c->bterms.p;
       B7_TRY(launch_fro_norm_sq(c, Kb, N, n, fro_dev));
       double fro = 0.0;
       B7_HIP(c, hipMemcpyAsync(&fro, fro_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -964,8 +964,15 @@ static int persist_launch(b7_ctx *c, PArgs a, int B, int mode, int helpers) {
     // the single fit: info, likelihood terms and flags are one block (b7_internal.h) -> one memset node
     B7_HIP(c, hipMemsetAsync(a.info, 0, B7_INFO_HEAD_BYTES + sizeof(unsigned) * persist_flag_words(a.nb), c->stream));
   } else {
-    B7_HIP(c, hipMemsetAsync(a.flags, 0, sizeof(unsigned) * (B > 1 ? (size_t)a.sflags * B : persist_flag_words(a.nb)), c->stream));
-    B7_HIP(c, hipMemsetAsync(a.info, 0, sizeof(int) * (B > 1 ? (size_t)a.sinfo * B : 4), c->stream));
+    const size_t flag_bytes = sizeof(unsigned) * (B > 1 ? (size_t)a.sflags * B : persist_flag_words(a.nb));
+    const size_t info_bytes = sizeof(int) * (B > 1 ? (size_t)a.sinfo * B : 4);
+    if (reinterpret_cast<char *>(a.flags) == reinterpret_cast<char *>(a.info) + info_bytes) {
+      // the caller laid the reports of this launch's fits right in front of their flags (b7_gp_nll_batch): one memset node
+      B7_HIP(c, hipMemsetAsync(a.info, 0, info_bytes + flag_bytes, c->stream));
+    } else {
+      B7_HIP(c, hipMemsetAsync(a.flags, 0, flag_bytes, c->stream));
+      B7_HIP(c, hipMemsetAsync(a.info, 0, info_bytes, c->stream));
+    }
   }
   a.with_inverse = mode == 1 ? 1 : 0;
   hipLaunchKernelGGL(potrf_persist_kernel, dim3(1 + helpers, B), dim3(256), PERSIST_LDS_BYTES, c->stream, a);

@@ -47,3 +47,24 @@ for d, N, fn in ((2, 24, benchmarks.braninhoo), (6, 64, benchmarks.hartmann6), (
                 line += " (C call %.1f us)" % ((time.perf_counter() - t0) / 500 * 1e6)
         line += " (rel err vs oracle %.1e)" % err
     print(line, flush=True)
+
+# above the one-workgroup kernel's range: the general path alone (observation scaling, K, fix-up, one persistent launch with the
+# vector job; hypers up and terms + reports back through the pinned block, one copy each way)
+c = ctxs["1"]
+for d, N in ((6, 200), (6, 500), (16, 1000), (32, 2048)):
+    X = c.grid_sobol(N, d, 2)
+    Y = benchmarks.hartmann6(X[:, :6]) if d >= 6 else benchmarks.braninhoo(X)
+    amp = float(np.var(Y))
+    c.gp_set_data(X, Y)
+    L = _lib.load()
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (np.full((1, d), d / 8.0), [amp], [1e-4 * amp], [float(np.mean(Y))])]
+    out = np.empty(1)
+    args = [c._h, 1] + [_lib._ptr(v) for v in a] + [_lib._ptr(out), None, None]
+    for _ in range(5):
+        L.b7_gp_nll_batch(*args)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        L.b7_gp_nll_batch(*args)
+    t = (time.perf_counter() - t0) / 200
+    want = float(gp.fit(X, Y, np.full(d, d / 8.0), amp, 1e-4 * amp, float(np.mean(Y))).nll[0])
+    print("d %2d N %4d:  general B= 1 C call %.1f us (rel err vs oracle %.1e)" % (d, N, t * 1e6, abs(out[0] - want) / abs(want)), flush=True)
