@@ -339,10 +339,11 @@ int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_
   PhaseScope ps(c, "potrf");
   B7_TRY(ensure_small_table(c));
   const size_t lds = sizeof(double) * NLL_SMALL_LDS_DOUBLES;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the opt-in to > 64 KiB of dynamic LDS is per device: once per process AND device (a process may hold contexts on several)
+  static bool attr_done[64] = {false};
+  if (c->device >= 64 || !attr_done[c->device]) {
     B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(nll_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    if (c->device < 64) attr_done[c->device] = true;
   }
   NllSmallInline hin = {};
   const int use_inline = (B == 1 && hyp_host != nullptr) ? 1 : 0;

@@ -785,6 +785,49 @@ def test_bayesopt_with_sampled_hypers_runs(ctx, orc):
     assert np.array_equal(ctx.grid_download(), np.asarray(bot.candidates))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_initial, budget", [(60, 69), (124, 132)])
+def test_sampled_hyper_loop_follows_the_oracle_driven_sampler_across_the_likelihood_paths(ctx, orc, n_initial, budget):
+    """model:sample_hypers (bots/bayesopt.lua:68,73-75) over samplers/slice.lua, whole trial loops whose observation count
+    crosses 64 (the one-workgroup likelihood kernel goes from one 64-block to two) and 128 (it hands over to the general
+    path): the same loop with every density evaluation answered by the ORACLE's likelihood instead must draw the same hypers
+    (to 1e-7: a slice sampler is continuous in its density away from accept / reject ties) and nominate the same candidates.
+    Oracle: parity unpinned (no reference fixture for the GP algebra)."""
+    import bot7_amd
+
+    class H(object):
+        def __init__(self, name):
+            self.name, self.min, self.max, self.size = name, 0.0, 1.0, 1
+
+    def run(oracle_density):
+        cfg = {"bot": {"verbose": 0, "budget": budget, "nInitial": n_initial, "nSamples": 2, "seed": 4},
+               "grid": {"type": "sobol", "size": 600, "dims": 2}, "score": {"type": "expected_improvement"},
+               "model": {"type": "gp_regressor", "sample": True, "nBurnin": 1, "seed": 6}}
+        bot = bots.bayesopt(B.braninhoo, [H("x1"), H("x2")], cfg)
+        bot.model._ctx = ctx
+        draws = []
+        if oracle_density:
+            bot.model.nll = lambda X, Y, hyp=None: orc.gp.fit(np.atleast_2d(X), np.asarray(Y).reshape(len(X), -1),
+                                                              **(hyp or bot.model.hyp)).nll
+        inner = bot.model.sample_hypers
+
+        def logged(*a, **k):
+            v = inner(*a, **k)
+            draws.append(np.array(v, dtype=np.float64))
+            return v
+        bot.model.sample_hypers = logged
+        bot.candidates = bot7_amd.grids.sobol(bot.config["grid"], context=ctx)()
+        bot.run_experiment()
+        return np.asarray(bot.observed).copy(), np.asarray(bot.responses).copy(), draws
+
+    obs_dev, resp_dev, draws_dev = run(False)
+    obs_orc, resp_orc, draws_orc = run(True)
+    assert obs_dev.shape == (budget, 2) and len(draws_dev) == len(draws_orc) and len(draws_dev) >= 3 * (budget - n_initial)
+    for k, (a, b) in enumerate(zip(draws_dev, draws_orc)):
+        assert np.allclose(a, b, rtol=1e-7, atol=1e-12), "hyper draw %d left the oracle-driven chain" % k
+    assert np.array_equal(obs_dev, obs_orc) and np.array_equal(resp_dev, resp_orc)
+
+
 # ---- fantasy columns and pending points (SURVEY 8f-2) ----------------------------------------------------------------
 def test_multi_column_fit_predict_and_ei(ctx, orc):
     """Y with c columns: K, L shared, alpha N x c, mean M x c, EI row-averaged (scores/expected_improvement.lua:83-85)."""
