@@ -2,11 +2,13 @@
 //
 // Reference: bots/bayesopt.lua:95-96 takes score:max(1) over ALL candidates.  With the grid sharded one process per
 // GPU every rank owns rows [offset, offset + M_local) and the same (value, 1-based global index) must
-// come out on every rank.  RCCL has no MAXLOC: each rank writes its own (value bits, global index) pair into a
-// zero-initialised [world, 2] table of 64-bit words and ONE ncclAllReduce(sum, uint64) over xGMI turns the table into
-// an all-gather (adding zeros is exact for every bit pattern: NaN payloads and -0.0 survive, indices are exact to
-// 2^63); every rank then applies TH's max rule on the host: the first NaN wins, else the largest value, ties to the
-// lowest global index.  32 B per rank, latency-bound: ring per-link bandwidth is irrelevant here.
+// come out on every rank.  RCCL has no MAXLOC: each rank writes its own record -- (value bits, global index, status, rows
+// in its shard, the grid row the index names: B7_TAB_W 64-bit words, b7_internal.h) -- into a zero-initialised
+// [world][B7_TAB_W] table and ONE ncclAllReduce(sum, uint64) over xGMI turns the table into an all-gather (adding zeros is
+// exact for every bit pattern: NaN payloads and -0.0 survive, indices are exact to 2^63); every rank then applies TH's max
+// rule on the host: the first NaN wins, else the largest value, ties to the lowest global index.  The row rides along so
+// that the trial loop's `steal` (b7_nominate_commit) needs no second collective; a rank that failed locally sends a
+// status record instead of staying away.  800 B per rank, latency-bound: ring per-link bandwidth is irrelevant here.
 //
 // librccl is resolved lazily (dlopen at the first b7_comm_* call): a single-GPU user never maps its 570 MB, and a
 // host that already carries an RCCL (e.g. the one torch bundles, same SONAME) shares that copy.
