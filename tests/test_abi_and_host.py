@@ -232,3 +232,29 @@ def test_posterior_accumulators_stay_out_of_the_compilers_hands():
     for nj, tiles in ((2, 16), (4, 32), (16, 32)):   # 128- and 256-candidate workgroups on 128-row n-tiles; the tall shape
         st = stats[nj]
         assert st["mfma"] >= 34 * tiles and st["mfma_from_zero"] == tiles and st["acc_reads"] == 8 * tiles and st["scratch"] == 0
+
+
+def test_every_entry_point_refuses_null_arguments_without_crashing():
+    """The boundary is plain C: a host that passes a NULL handle / NULL pointers / zero sizes (a LuaJIT cdata that was never
+    filled in) must get an error code back from every one of the exports, not a segmentation fault.  Run in a child
+    process so that a crash would fail this test instead of ending the run."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from bot7_amd import _lib
+L = _lib.load()
+bad = []
+for name in _lib.SYMBOLS:
+    fn = getattr(L, name)
+    args = [0 if t in (C.c_int, C.c_int64, C.c_uint64) else (0.0 if t is C.c_double else None) for t in fn.argtypes]
+    rc = fn(*args)
+    if fn.restype is C.c_int and name != "b7_abi_version" and not rc < 0:
+        bad.append((name, rc))
+assert not bad, bad
+print("swept", len(_lib.SYMBOLS))
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr[-800:])
+    assert "swept %d" % len(_lib.SYMBOLS) in out.stdout
