@@ -1990,3 +1990,14 @@ def test_small_set_likelihood_kernel_equals_the_general_path_and_the_oracle(orc,
     assert float(model.nll(Xs, -Ys, h)[0]) != v1     # new data of the same shape are noticed (content key)
     small.close()
     general.close()
+
+
+def test_live_handles_with_null_arguments_never_crash():
+    """tools/null_sweep_gpu.py: every export called with a live context (fresh, then fitted and predicted) or a live group and
+    NULL pointers / zero sizes everywhere else.  Error codes or harmless successes, never a fault (child process)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                                        "null_sweep_gpu.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-400:], out.stderr[-400:])
+    assert "calls without a crash" in out.stdout
