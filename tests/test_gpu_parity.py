@@ -2001,3 +2001,30 @@ def test_live_handles_with_null_arguments_never_crash():
                                                         "null_sweep_gpu.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.returncode, out.stdout[-400:], out.stderr[-400:])
     assert "calls without a crash" in out.stdout
+
+
+@pytest.mark.parametrize("d,N,M", [(1, 1, 1), (1, 1, 5), (3, 1, 300), (1, 2, 1), (96, 3, 2), (96, 130, 257), (64, 1, 129),
+                                   (2, 128, 1), (39, 1, 1)])
+def test_extreme_shapes_match_oracle(ctx, orc, d, N, M):
+    """One observation, one candidate, one dimension, the widest input (96), and their mixes: fit, likelihood (both
+    entry points), posterior and the nomination against the oracle (parity unpinned: no reference fixture for the GP algebra)."""
+    rng = np.random.default_rng(1000 * d + 10 * N + M)
+    X, Y, Xh = rng.random((N, d)), rng.normal(size=(N, 1)), rng.random((M, d))
+    hyp = dict(lenscale_sq=np.full(d, max(d / 8.0, 0.2)), amp=1.3, noise=1e-3, mean=0.1)
+    f = orc.gp.fit(X, Y, **hyp)
+    out = ctx.gp_fit(X, Y, hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"], want_nll=True)
+    assert out["info"] == 0 and out["nll"][0] == pytest.approx(float(f.nll[0]), rel=1e-9, abs=1e-9)
+    ctx.grid_upload(Xh)
+    mu, var = ctx.gp_predict()
+    mu_o, var_o = orc.gp.predict(f, Xh)
+    assert relerr(mu, mu_o, floor=1e-3 * max(1e-300, np.abs(mu_o).max())) < REL and relerr(var, var_o) < REL
+    ctx.gp_set_data(X, Y)
+    assert ctx.gp_nll_batch(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])[0] == pytest.approx(float(f.nll[0]), rel=1e-9, abs=1e-9)
+    v, i = ctx.eval_nominate([hyp], score="ei", fmin=[float(Y.min())])
+    acc = np.zeros(M)
+    orc.c.accumulate(acc, orc.c.ei(mu_o, var_o, [float(Y.min())], 0.0))
+    orc.c.divide(acc, 1.0)
+    io, vo = orc.c.argmax_first(acc)
+    top2 = np.sort(acc)[-2:] if M > 1 else None
+    if M == 1 or top2[1] - top2[0] > 1e-9 * max(abs(top2[1]), 1e-300):
+        assert i == io
