@@ -99,12 +99,31 @@ def make_inputs(ctx, d, N, M_total, lo, hi):
     return X_obs
 
 
+def usable_cores():
+    """Threads this process can actually run at once: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a container on a 256-core host with cpu.max = 16 CPUs runs 16 threads' worth, whatever the mask says)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if quota != "max":
+            cores = max(1, min(cores, int(-(-int(quota) // int(period)))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())              # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                cores = max(1, min(cores, -(-quota // period)))
+        except Exception:
+            pass
+    return cores
+
+
 def cpu_baseline(d, N, score, X_obs, Y, hyp, X_hid, window0=0):
     """The oracle (port of the Torch7 CPU path: BLAS dgemm / LAPACK dpotrf / dtrtrs through numpy+scipy) timed on
     this box's host cores on a bounded sample of the same workload: one fit + len(X_hid) candidates, rows
     [window0, window0 + len(X_hid)) of rank 0's shard -- the window that holds the GPU's global winner."""
     from oracle import cport, gp
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=cores)
