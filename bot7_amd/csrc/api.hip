@@ -930,10 +930,12 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   // pinned staging: [S][4] pivot reports | hypers of all S samples ([S][d] lengthscales, then S amp, S noise, S mean)
   const size_t hyp_doubles = (size_t)S * (d + 3), ls_bytes = sizeof(double) * hyp_doubles, rep_bytes = 16 * (size_t)S;
   if (c->pin_eval_bytes < ls_bytes + rep_bytes) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));  // nothing in flight writes reports into the block about to go
     if (c->pin_eval) (void)hipHostFree(c->pin_eval);
     c->pin_eval = nullptr;
     c->pin_eval_bytes = 0;
-    B7_HIP(c, hipHostMalloc(&c->pin_eval, 2 * (ls_bytes + rep_bytes), hipHostMallocDefault));
+    B7_HIP(c, hipHostMalloc(&c->pin_eval, 2 * (ls_bytes + rep_bytes), hipHostMallocMapped));
+    B7_HIP(c, hipHostGetDevicePointer(&c->pin_eval_dev, c->pin_eval, 0));
     c->pin_eval_bytes = 2 * (ls_bytes + rep_bytes);
   }
   B7_TRY(b7_ensure(c, c->bhyp, ls_bytes));
@@ -969,7 +971,7 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   double *fd = nullptr;
   if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
 
-  B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69
+  c->acc_fresh = true;  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69: declared, not launched -- the first score:add starts from 0.0
   c->acc_valid = true;
   if (batch) {
     const double *hyp_dev = (const double *)c->bhyp.p, *amp_dev = hyp_dev + (size_t)S * d, *noise_dev = amp_dev + S,
@@ -980,8 +982,14 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
                             (double *)c->bK.p));
     B7_TRY(launch_fit_batch(c, S, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bLinv.p, (double *)c->bdinv.p,
                             (unsigned *)c->bflags.p, (int *)c->binfo.p));
-    B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p));
-    B7_HIP(c, hipMemcpyAsync(reports, c->binfo.p, rep_bytes, hipMemcpyDeviceToHost, c->stream));
+    int *reports_dev = static_cast<int *>(c->pin_eval_dev);
+    if (4 * S <= 256) {  // the reports ride on the last kernel of the fits into the mapped block: no copy launch
+      B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p,
+                                (const int *)c->binfo.p, reports_dev, 4 * S));
+    } else {
+      B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p));
+      B7_HIP(c, hipMemcpyAsync(reports, c->binfo.p, rep_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     const size_t row_bytes = sizeof(double) * (size_t)n;
     const int64_t Mpad = round_up(c->M, B7_MROWS);
     if ((size_t)Mpad * S * row_bytes <= c->ks_bytes) {
@@ -1033,8 +1041,7 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
       B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
       B7_TRY(launch_potrf(c, 0.0, true));
       if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
-      B7_TRY(launch_alpha(c));
-      B7_HIP(c, hipMemcpyAsync(reports + 4 * s, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
+      B7_TRY(launch_alpha(c, static_cast<int *>(c->pin_eval_dev) + 4 * s, 4));  // + this fit's pivot report, no copy launch
       c->fitted = true;
       B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
       c->predicted = true;
@@ -1065,6 +1072,7 @@ bool eval_reports_clean(b7_ctx *c, int S) {
 int eval_redo(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec, double *jitter_out, int *info_out) {
   B7_HIP(c, hipSetDevice(c->device));
   B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));
+  c->acc_fresh = false;
   double *fd = nullptr;
   for (int s = 0; s < S; ++s) {
     B7_TRY(fit_hyp_core(c, &hyps[s], nullptr, jitter_out ? jitter_out + s : nullptr, info_out ? info_out + s : nullptr, true));
@@ -1093,14 +1101,12 @@ int b7_eval_nominate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *
     // the arg-max and the copy of its record are enqueued before the host has seen any report: one synchronisation
     B7_TRY(rc);
     B7_TRY(eval_enqueue(c, S, hyps, spec));
-    B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true));
-    B7_TRY(exch_fetch(c, 0, world));
-    B7_HIP(c, hipStreamSynchronize(c->stream));
+    B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true, true));  // record mirrored into mapped host memory
+    B7_TRY(exch_wait_mirror(c));
     if (!eval_reports_clean(c, S)) {
       B7_TRY(eval_redo(c, S, hyps, spec, jitter_out, info_out));
-      B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true));
-      B7_TRY(exch_fetch(c, 0, world));
-      B7_HIP(c, hipStreamSynchronize(c->stream));
+      B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true, true));
+      B7_TRY(exch_wait_mirror(c));
     }
     return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
   }
@@ -1753,15 +1759,13 @@ int b7_blr_eval_nominate(b7_ctx *c, const b7_mlp *net, const double *X0, const d
   if (!exchange) {
     B7_TRY(rc);
     B7_TRY(local());
-    B7_TRY(exch_local(c, 1.0, global_row_offset, rank, world, true));
-    B7_TRY(exch_fetch(c, 0, world));
-    B7_HIP(c, hipStreamSynchronize(c->stream));
+    B7_TRY(exch_local(c, 1.0, global_row_offset, rank, world, true, true));
+    B7_TRY(exch_wait_mirror(c));
     if (report[0] != 0 || report[1] != 0) {
       if (report[1] != 0) persist_gave_up(c);
       B7_TRY(redo());
-      B7_TRY(exch_local(c, 1.0, global_row_offset, rank, world, true));
-      B7_TRY(exch_fetch(c, 0, world));
-      B7_HIP(c, hipStreamSynchronize(c->stream));
+      B7_TRY(exch_local(c, 1.0, global_row_offset, rank, world, true, true));
+      B7_TRY(exch_wait_mirror(c));
     }
     return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
   }
@@ -1792,6 +1796,7 @@ int b7_score_reset(b7_ctx *c) {
   B7_HIP(c, hipSetDevice(c->device));
   B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
   B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69
+  c->acc_fresh = false;
   c->acc_valid = true;
   return B7_OK;
 }
@@ -1829,6 +1834,7 @@ int b7_score_finish(b7_ctx *c, double divisor, double *best_val, int64_t *best_i
   if (!c) return B7_ERR_INVALID;
   if (!c->acc_valid) return b7_fail(c, B7_ERR_STATE, "score_finish: call b7_score_reset first");
   B7_HIP(c, hipSetDevice(c->device));
+  B7_TRY(acc_materialize(c));
   B7_TRY(launch_finish(c, (double *)c->acc.p, c->M, divisor, best_val, best_idx1));
   if (scores_host) {
     B7_HIP(c, hipMemcpyAsync(scores_host, c->acc.p, sizeof(double) * (size_t)c->M, hipMemcpyDeviceToHost, c->stream));

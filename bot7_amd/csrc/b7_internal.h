@@ -92,6 +92,7 @@ struct b7_ctx {
   DevBuf var;    // M
   DevBuf acc;    // M score accumulator
   bool acc_valid = false;
+  bool acc_fresh = false;  // the accumulator stands for zeros that were never written: the next score launch onto it starts from 0.0
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain with the DPP-fused
@@ -104,6 +105,7 @@ struct b7_ctx {
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
   std::vector<double> net_host;  // the basis network last uploaded to netbuf (packed W, b per layer)
+  void *pin_eval_dev = nullptr;  // device address of pin_eval (mapped)
   void *pin_eval = nullptr;  // b7_eval_nominate: [S][4] pivot reports + [S][d] lengthscale staging (pinned)
   size_t pin_eval_bytes = 0;
   void *pinned_dev = nullptr;
@@ -149,7 +151,8 @@ struct b7_ctx {
   void *comm = nullptr;  // ncclComm_t
   int comm_rank = 0, comm_world = 1;
   DevBuf slots;  // [world, B7_TAB_W] x u64 exchange table (also the staging of b7_comm_allreduce_f64)
-  uint64_t *tab_host = nullptr;  // pinned host copy of the table, B7_MAX_WORLD records
+  uint64_t *tab_host = nullptr;  // pinned, device-mapped host copy of the table: B7_MAX_WORLD records, a staging record, the completion word
+  uint64_t *tab_host_dev = nullptr;  // its device address
   struct b7_group *group = nullptr;  // set while the context is a member of a single-process group (group.hip)
   bool group_busy = false;           // ... and this while the group itself is calling the member's grid mutators
   // the last exchange as every rank saw it: the winner (index, owning rank, grid row) and the row count of every shard.
@@ -260,8 +263,10 @@ size_t persist_flag_words_host(int nb);
 bool nll_small_applies(const b7_ctx *c);
 int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
                      unsigned *done_dev);
-int launch_alpha(b7_ctx *c);           // resid, Linv -> alpha
-int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha);  // B single-column fits
+// report_dev (nullable): device address of mapped host memory that receives the first report_words ints of the pivot report
+int launch_alpha(b7_ctx *c, int *report_dev = nullptr, int report_words = 0);  // resid, Linv -> alpha
+int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha, const int *report_src = nullptr,
+                       int *report_dev = nullptr, int report_words = 0);  // B single-column fits
 int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, unsigned *flags, int *info);
 int launch_nll_terms(b7_ctx *c, double *out_dev);  // out[0] = sum log L_ii, out[1 + k] = r_k' alpha_k
 int launch_fro_norm_sq(b7_ctx *c, const double *A, int n, int ld, double *out_dev);  // sum of squares of A[0:n, 0:n]
@@ -302,7 +307,8 @@ int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, i
 int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *best_val, int64_t *best_idx1);
 int launch_fill(b7_ctx *c, double *p, int64_t n, double v);
 int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64_t *tab_dev, int rank, int world,
-                       int64_t offset, const double *grid, int d, bool all_slots);
+                       int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec = nullptr,
+                       unsigned *host_done = nullptr);
 
 int launch_keep_record(b7_ctx *c, uint64_t *tab_dev, int rank, int world);
 int launch_row_slot(b7_ctx *c, uint64_t *tab_dev, int rank, int world, int64_t idx1_global, int64_t local0, const double *grid,
@@ -311,7 +317,9 @@ int launch_row_slot(b7_ctx *c, uint64_t *tab_dev, int rank, int world, int64_t i
 // comm.hip: the pieces of a sharded nomination that b7_eval_nominate, b7_score_finish_global and the single-process
 // group (group.hip) are assembled from
 int exch_table_ensure(b7_ctx *c, int world);
-int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots);  // enqueue: score:div, local arg-max, this rank's record
+int acc_materialize(b7_ctx *c);  // acc_fresh -> real zeros (before anything reads the accumulator)
+int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots, bool mirror = false);
+int exch_wait_mirror(b7_ctx *c);  // after exch_local(..., mirror = true): spin on the completion word, then (or instead, when it takes long) the stream  // enqueue: score:div, local arg-max, this rank's record
 int exch_fail_record(b7_ctx *c, int rank, int world, int code);  // enqueue: this rank's record says "could not score"
 int exch_allreduce(b7_ctx *c);                                   // enqueue: the collective (no-op without a communicator)
 int exch_rewrite_record(b7_ctx *c, int rank, int world);         // enqueue: zero every record but this rank's (before a repeated all-reduce)

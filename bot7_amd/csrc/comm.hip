@@ -16,6 +16,8 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "b7_internal.h"
 #include "comm_rccl.h"
 
@@ -58,18 +60,51 @@ Rccl &rccl() {
 int exch_table_ensure(b7_ctx *c, int world) {
   if (world < 1 || world > B7_MAX_WORLD) return b7_fail(c, B7_ERR_UNSUPPORTED, "exchange: world %d not in [1, %d]", world, B7_MAX_WORLD);
   B7_TRY(b7_ensure(c, c->slots, sizeof(uint64_t) * B7_TAB_W * (size_t)world + sizeof(double) * 128 + 64));
-  if (!c->tab_host) B7_HIP(c, hipHostMalloc((void **)&c->tab_host, sizeof(uint64_t) * B7_TAB_W * (B7_MAX_WORLD + 1), hipHostMallocDefault));  // + one staging record
+  if (!c->tab_host) {  // + one staging record + the record whose first word is the mirror's completion word
+    B7_HIP(c, hipHostMalloc((void **)&c->tab_host, sizeof(uint64_t) * B7_TAB_W * (B7_MAX_WORLD + 2), hipHostMallocMapped));
+    B7_HIP(c, hipHostGetDevicePointer((void **)&c->tab_host_dev, c->tab_host, 0));
+  }
   return B7_OK;
+}
+
+static volatile unsigned *mirror_done_word(b7_ctx *c) {
+  return reinterpret_cast<volatile unsigned *>(c->tab_host + (size_t)(B7_MAX_WORLD + 1) * B7_TAB_W);
 }
 
 void exch_forget(b7_ctx *c) { c->win_valid = false; }
 
 // score:div + local score:max(1) on the device; this rank's record lands in the table with the index already global
 // and the grid row it names beside it (an empty shard contributes a zero record)
-int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots) {
+// mirror: the kernel also writes this rank's record into the mapped host table and raises the completion word behind it
+// (a context that nominates by itself: no copy launch and no stream wait between the arg-max and the answer; exch_wait_mirror)
+int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots, bool mirror) {
   B7_TRY(exch_table_ensure(c, world));
+  if (c->M > 0) B7_TRY(acc_materialize(c));
+  uint64_t *host_rec = nullptr;
+  unsigned *host_done = nullptr;
+  if (mirror) {
+    *mirror_done_word(c) = 0u;
+    host_rec = c->tab_host_dev + (size_t)rank * B7_TAB_W;
+    host_done = reinterpret_cast<unsigned *>(c->tab_host_dev + (size_t)(B7_MAX_WORLD + 1) * B7_TAB_W);
+  }
   return launch_finish_slot(c, c->M > 0 ? (double *)c->acc.p : nullptr, c->M, divisor, (uint64_t *)c->slots.p, rank, world,
-                            offset, c->M > 0 ? (const double *)c->grid[c->grid_cur].p : nullptr, c->d, all_slots);
+                            offset, c->M > 0 ? (const double *)c->grid[c->grid_cur].p : nullptr, c->d, all_slots, host_rec,
+                            host_done);
+}
+
+// Everything enqueued before the mirrored arg-max has completed once its word is up (one stream).  Short nominations are
+// answered while the host is still spinning; after 500 us the ordinary stream wait takes over (it also surfaces faults).
+int exch_wait_mirror(b7_ctx *c) {
+  volatile unsigned *done = mirror_done_word(c);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(const_cast<const unsigned *>(done), __ATOMIC_ACQUIRE) != 0u) return B7_OK;
+    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+  }
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (__atomic_load_n(const_cast<const unsigned *>(done), __ATOMIC_ACQUIRE) == 0u)
+    return b7_fail(c, B7_ERR_HIP, "nomination: the arg-max kernel finished without raising its completion word");
+  return B7_OK;
 }
 
 // A rank that could not score its shard still takes part in the collective: its record carries the error code, and
@@ -258,7 +293,7 @@ int b7_score_finish_global(b7_ctx *c, double divisor, int64_t global_row_offset,
   if (global_row_offset < 0) rc = b7_fail(c, B7_ERR_INVALID, "score_finish_global: negative row offset");
   else if (c->M > 0 && !c->acc_valid) rc = b7_fail(c, B7_ERR_STATE, "score_finish_global: call b7_score_reset first");
   if (rc == B7_OK) rc = hipSetDevice(c->device) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "hipSetDevice failed");
-  if (rc == B7_OK) rc = exch_local(c, divisor, global_row_offset, rank, world, true);
+  if (rc == B7_OK) rc = exch_local(c, divisor, global_row_offset, rank, world, true, !c->comm);
   if (rc != B7_OK) {
     if (world == 1) return rc;
     const std::string own = c->err;
@@ -268,6 +303,10 @@ int b7_score_finish_global(b7_ctx *c, double divisor, int64_t global_row_offset,
     exch_forget(c);
     c->err = own;
     return rc;
+  }
+  if (!c->comm) {  // no communicator, nobody to exchange with: the record went straight to the mapped host table
+    B7_TRY(exch_wait_mirror(c));
+    return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
   }
   B7_TRY(exch_allreduce(c));
   B7_TRY(exch_fetch(c, 0, world));

@@ -524,7 +524,11 @@ __global__ void __launch_bounds__(256)
 }
 __global__ void __launch_bounds__(256)
     trmv_lower_t_sum_kernel(const double *__restrict__ part, double *__restrict__ alpha, int n, int nreal, int ycols,
-                            int yld, int nslices, int64_t st = 0, int64_t salpha = 0) {
+                            int yld, int nslices, int64_t st = 0, int64_t salpha = 0, const int *__restrict__ rep_src = nullptr,
+                            int *__restrict__ rep_dst = nullptr, int rep_words = 0) {
+  // the last kernel of a fit hands the factorisation's pivot reports to mapped host memory on its way (the factorisation
+  // before it on the stream is complete): a 16-byte copy launch per fit less
+  if (rep_dst && blockIdx.x == 0 && blockIdx.z == 0 && (int)threadIdx.x < rep_words) rep_dst[threadIdx.x] = rep_src[threadIdx.x];
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= n) return;
   part += blockIdx.z * st;
@@ -776,7 +780,7 @@ int launch_nll_terms(b7_ctx *c, double *out_dev) {
   return B7_OK;
 }
 
-int launch_alpha(b7_ctx *c) {
+int launch_alpha(b7_ctx *c, int *report_dev, int report_words) {
   const int n = c->Npad;
   const int nslices = (n + TSL - 1) / TSL;
   // t = Linv * resid (n x ycols) and the nslices x ycols x n slice partials of Linv' * t live in a buffer of their
@@ -790,13 +794,15 @@ int launch_alpha(b7_ctx *c) {
   hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices), dim3(256), 0, c->stream,
                      (const double *)c->Linv.p, (const double *)t, part, n, c->ycols);
   hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double *)part,
-                     (double *)c->alpha.p, n, c->N, c->ycols, c->yld, nslices);
+                     (double *)c->alpha.p, n, c->N, c->ycols, c->yld, nslices, (int64_t)0, (int64_t)0, (const int *)c->info.p,
+                     report_dev, report_dev ? report_words : 0);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
 
 // alpha_b = Linv_b' (Linv_b r_b) for B single-column fits at once (grid.z = fit); the same kernels, the same sums
-int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha) {
+int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha, const int *report_src,
+                       int *report_dev, int report_words) {
   const int n = c->Npad;
   const int nslices = (n + TSL - 1) / TSL;
   const int64_t st = (int64_t)n * (1 + nslices), nn = (int64_t)n * n;
@@ -807,7 +813,7 @@ int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid
   hipLaunchKernelGGL(trmv_lower_t_part_kernel, dim3(n / 64, nslices, B), dim3(256), 0, c->stream, Linv, (const double *)t,
                      t + n, n, 1, nn, st);
   hipLaunchKernelGGL(trmv_lower_t_sum_kernel, dim3((n + 255) / 256, 1, B), dim3(256), 0, c->stream, (const double *)(t + n),
-                     alpha, n, c->N, 1, 1, nslices, st, (int64_t)n);
+                     alpha, n, c->N, 1, 1, nslices, st, (int64_t)n, report_src, report_dev, report_dev ? report_words : 0);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256)
       acc = (c == 1) ? ei : acc + ei;
     }
     double v = (c == 1) ? acc : acc / (double)c;
-    out[j] = accumulate ? out[j] + v : v;
+    out[j] = accumulate == 1 ? out[j] + v : (accumulate == 2 ? 0.0 + v : v);  // 2: the first score:add onto torch.zeros
   }
 }
 
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256)
     }
     double val = (c == 1) ? acc : acc / (double)c;
     val = (sign > 0.0) ? val : -val;
-    out[j] = accumulate ? out[j] + val : val;
+    out[j] = accumulate == 1 ? out[j] + val : (accumulate == 2 ? 0.0 + val : val);
   }
 }
 
@@ -80,10 +80,10 @@ __global__ void __launch_bounds__(256)
 // what S score:add calls leave (bots/bayesopt.lua:76)
 __global__ void __launch_bounds__(256)
     ei_batch_kernel(const double *__restrict__ mu, const double *__restrict__ var, int S, int64_t sstride,
-                    const double *__restrict__ fmin, double xi, int64_t M, double *__restrict__ out) {
+                    const double *__restrict__ fmin, double xi, int64_t M, double *__restrict__ out, int fresh) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
-    double a = out[j];
+    double a = fresh ? 0.0 : out[j];  // fresh: the accumulator is torch.zeros (bots/bayesopt.lua:69), not read
     for (int s = 0; s < S; ++s) {
       double sigma = sqrt(var[s * sstride + j]);
       double imprv = (fmin[0] + (-mu[s * sstride + j])) + (-xi);
@@ -97,10 +97,10 @@ __global__ void __launch_bounds__(256)
 }
 __global__ void __launch_bounds__(256)
     cb_batch_kernel(const double *__restrict__ mu, const double *__restrict__ var, int S, int64_t sstride, double kappa,
-                    int upper, double sign, int64_t M, double *__restrict__ out) {
+                    int upper, double sign, int64_t M, double *__restrict__ out, int fresh) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
-    double a = out[j];
+    double a = fresh ? 0.0 : out[j];
     for (int s = 0; s < S; ++s) {
       double sd = sqrt(var[s * sstride + j]) * kappa;
       double v = upper ? (mu[s * sstride + j] + sd) : (mu[s * sstride + j] + (-sd));
@@ -183,7 +183,8 @@ __global__ void __launch_bounds__(256) argmax_final_kernel(const Best *__restric
 __global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict__ part, int n, unsigned long long *__restrict__ tab,
                                                           int rank, int world, long long offset, long long rows,
                                                           const double *__restrict__ grid, int d, int all_slots,
-                                                          long long forced_local) {
+                                                          long long forced_local, unsigned long long *__restrict__ host_rec,
+                                                          unsigned *__restrict__ host_done) {
   __shared__ Best sh[4];
   Best b{0.0, -1};
   if (n > 0) {
@@ -206,6 +207,14 @@ __global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict
     else if (e >= B7_TAB_ROW0 && e - B7_TAB_ROW0 < d && have && grid)
       w = (unsigned long long)__double_as_longlong(grid[b.i * d + (e - B7_TAB_ROW0)]);
     rec[e] = w;
+    if (host_rec) host_rec[e] = w;  // the same record straight into mapped host memory: no copy launch behind this kernel
+  }
+  if (host_done) {
+    // the host spins on this word instead of waiting for the stream: every thread's part of the record is pushed out to
+    // system scope before the barrier, thread 0's release store comes after it
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -221,12 +230,21 @@ int nblocks(b7_ctx *c, int64_t n) {
 
 }  // namespace
 
+// 0: out = score; 1: out += score; 2: out = 0.0 + score -- the context's accumulator was declared torch.zeros without being
+// filled (b7_eval_nominate: bots/bayesopt.lua:69 costs no launch of its own) and this is the first score:add onto it
+static int acc_mode(b7_ctx *c, const double *out, bool accumulate) {
+  if (out != (const double *)c->acc.p) return accumulate ? 1 : 0;
+  const bool fresh = c->acc_fresh;
+  c->acc_fresh = false;
+  return accumulate ? (fresh ? 2 : 1) : 0;
+}
+
 int launch_ei(b7_ctx *c, const double *mu, const double *var, const double *fmin_dev, double tradeoff, int64_t M,
               int ycols, double *out, bool accumulate) {
   PhaseScope ps(c, "score");
   if (M <= 0) return B7_OK;
   hipLaunchKernelGGL(ei_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, fmin_dev, tradeoff, M, ycols,
-                     out, accumulate ? 1 : 0);
+                     out, acc_mode(c, out, accumulate));
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -236,7 +254,7 @@ int launch_cb(b7_ctx *c, const double *mu, const double *var, double tradeoff, i
   PhaseScope ps(c, "score");
   if (M <= 0) return B7_OK;
   hipLaunchKernelGGL(cb_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, tradeoff, upper, sign, M,
-                     ycols, out, accumulate ? 1 : 0);
+                     ycols, out, acc_mode(c, out, accumulate));
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -246,7 +264,7 @@ int launch_ei_batch(b7_ctx *c, int S, const double *mu, const double *var, int64
   PhaseScope ps(c, "score");
   if (M <= 0) return B7_OK;
   hipLaunchKernelGGL(ei_batch_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, S, stride, fmin_dev, tradeoff, M,
-                     acc);
+                     acc, acc_mode(c, acc, true) == 2 ? 1 : 0);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -256,7 +274,7 @@ int launch_cb_batch(b7_ctx *c, int S, const double *mu, const double *var, int64
   PhaseScope ps(c, "score");
   if (M <= 0) return B7_OK;
   hipLaunchKernelGGL(cb_batch_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, S, stride, tradeoff, upper, sign,
-                     M, acc);
+                     M, acc, acc_mode(c, acc, true) == 2 ? 1 : 0);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -266,6 +284,13 @@ int launch_fill(b7_ctx *c, double *p, int64_t n, double v) {
   hipLaunchKernelGGL(fill_kernel, dim3(nblocks(c, n)), dim3(256), 0, c->stream, p, n, v);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
+}
+
+// zeros that were only declared (acc_fresh) and never met a score launch: write them before anybody reads the accumulator
+int acc_materialize(b7_ctx *c) {
+  if (!c->acc_fresh) return B7_OK;
+  c->acc_fresh = false;
+  return launch_fill(c, (double *)c->acc.p, c->M, 0.0);
 }
 
 int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *best_val, int64_t *best_idx1) {
@@ -288,8 +313,10 @@ int launch_finish(b7_ctx *c, double *acc, int64_t M, double divisor, double *bes
 
 // launch_finish without the host round trip: the local result stays on the device, in this rank's record of the
 // exchange table, together with the grid row it names.  M == 0 (an empty shard) writes an all-zero record.
+// host_rec / host_done (nullable): device addresses of a mapped host copy of this rank's record and of the word the kernel
+// sets once that copy is complete (comm.hip: exch_local with a mirror).
 int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64_t *tab_dev, int rank, int world,
-                       int64_t offset, const double *grid, int d, bool all_slots) {
+                       int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec, unsigned *host_done) {
   PhaseScope ps(c, "argmax");
   const int nb = M > 0 ? nblocks(c, M) : 0;
   B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
@@ -297,7 +324,7 @@ int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64
   if (nb > 0) hipLaunchKernelGGL(finish_kernel, dim3(nb), dim3(256), 0, c->stream, acc, M, divisor, part);
   hipLaunchKernelGGL(argmax_slot_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb,
                      (unsigned long long *)tab_dev, rank, world, (long long)offset, (long long)M, grid, d, all_slots ? 1 : 0,
-                     -1ll);
+                     -1ll, (unsigned long long *)host_rec, host_done);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -308,7 +335,7 @@ int launch_row_slot(b7_ctx *c, uint64_t *tab_dev, int rank, int world, int64_t i
                     int d) {
   hipLaunchKernelGGL(argmax_slot_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)nullptr, 0,
                      (unsigned long long *)tab_dev, rank, world, (long long)(idx1_global - 1 - (local0 >= 0 ? local0 : 0)),
-                     (long long)c->M, grid, d, 1, (long long)local0);
+                     (long long)c->M, grid, d, 1, (long long)local0, (unsigned long long *)nullptr, (unsigned *)nullptr);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
