@@ -318,7 +318,9 @@ int b7_exchange_info(b7_ctx *ctx, int *world, int64_t *rows_per_rank, int64_t *w
  * resident grid, then score:max(1) -- across ranks when the context has a communicator, exactly as
  * b7_score_finish_global.  Same results as the loop  { b7_gp_predict_hyp(hyp_s); b7_score_ei|cb } x S  +
  * b7_score_finish_global(S, offset), bit for bit, but all S fits, posteriors and score:adds are enqueued back to
- * back and the host synchronises once: each fit's pivot report is checked afterwards, and a failed pivot (or a
+ * back and the host waits once (without a communicator: on a word the arg-max kernel raises behind its record in mapped
+ * host memory, so the call may return a moment before the stream is formally idle -- later calls queue behind it as always,
+ * b7_sync waits for the stream): each fit's pivot report is checked afterwards, and a failed pivot (or a
  * hand-off time-out) redoes the nomination through the per-sample path with utils/math.lua:159-218's jitter
  * schedule.  With S > 1 and one response column the S fits run SIDE BY SIDE in one persistent launch (one critical
  * workgroup each): a fit's dependent chain leaves most of the chip idle, so ten fits cost little more than one;
