@@ -160,7 +160,6 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
-  if (const char *pv = getenv("B7_BLR_ASIDE")) c->blr_aside = atoi(pv) != 0;  // 0: candidates' features behind the fit on one stream
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
   c->persist_stamps = getenv("B7_PERSIST_STAMPS") != nullptr;
@@ -218,9 +217,6 @@ void b7_destroy(b7_ctx *c) {
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->phase_e0) (void)hipEventDestroy(c->phase_e0);
   if (c->ev_fit) (void)hipEventDestroy(c->ev_fit);
-  if (c->ev_side_go) (void)hipEventDestroy(c->ev_side_go);
-  if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1699,43 +1695,16 @@ static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const
 }
 
 // features of the resident grid (recomputed, as models/dngo.lua:155-171 does on every predict), mean, variance, score
-// The candidates' features do not depend on the fit: they are enqueued on a side stream BEFORE the fit's chain of small
-// kernels (features of the observations, a 50 x 50 system, its factorisation, three matrix-vector launches: ~0.1 ms in which
-// almost the whole chip idles) and run beside it; the main stream picks them up through an event.  The price is the mean as a
-// pass of its own over the features (the fused form needs the fit's weights at the time the features are made).
-static int blr_enqueue_features_aside(b7_ctx *c, const b7_mlp *net, int z) {
-  const int zpad = (int)round_up(z, B7_NPAD);
-  if (!c->stream2) {
-    B7_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    B7_HIP(c, hipEventCreateWithFlags(&c->ev_side_go, hipEventDisableTiming));
-    B7_HIP(c, hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
-  }
-  B7_TRY(feat_alloc(c, c->M, z));  // (re)layout zeroing, if any, is main-stream work in front of the event
-  B7_HIP(c, hipEventRecord(c->ev_side_go, c->stream));  // the grid, the network and the feature buffer are as the main stream left them
-  B7_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_side_go, 0));
-  hipStream_t main_stream = c->stream;
-  c->stream = c->stream2;  // the launchers (and their phase events) use the context's stream
-  const int rc = launch_mlp_forward_mean(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p, net->dims,
-                                         net->n_layers, net->activation, (double *)c->feat.p, zpad, nullptr, 0.0, nullptr, nullptr);
-  c->stream = main_stream;
-  B7_TRY(rc);
-  B7_HIP(c, hipEventRecord(c->ev_side_done, c->stream2));
-  return B7_OK;
-}
-
-static int blr_enqueue_score(b7_ctx *c, const b7_mlp *net, int z, const b7_score_spec *spec, bool features_aside = false) {
+static int blr_enqueue_score(b7_ctx *c, const b7_mlp *net, int z, const b7_score_spec *spec) {
   const int zpad = (int)round_up(z, B7_NPAD);
   B7_TRY(feat_alloc(c, c->M, z));
   B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M));
   B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
   B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
   bool mean_done = false;
-  if (features_aside)
-    B7_HIP(c, hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
-  else
-    B7_TRY(launch_mlp_forward_mean(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p, net->dims,
-                                   net->n_layers, net->activation, (double *)c->feat.p, zpad, (const double *)c->alpha.p, c->mean,
-                                   (double *)c->mu.p, &mean_done));
+  B7_TRY(launch_mlp_forward_mean(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p, net->dims,
+                                 net->n_layers, net->activation, (double *)c->feat.p, zpad, (const double *)c->alpha.p, c->mean,
+                                 (double *)c->mu.p, &mean_done));
   if (!mean_done)
     B7_TRY(launch_gemv_rows(c, (const double *)c->feat.p, c->Npad, (const double *)c->alpha.p, c->Npad, c->mean, 0, c->M, c->M,
                             (double *)c->mu.p));
@@ -1778,10 +1747,8 @@ int b7_blr_eval_nominate(b7_ctx *c, const b7_mlp *net, const double *X0, const d
   std::vector<double> rb;  // beta (Y - mean): the source of an asynchronous copy, alive until the synchronisation below
   auto local = [&]() -> int {
     if (c->M == 0) return B7_OK;   // an empty shard: nothing to score, but the exchange is collective
-    const bool aside = c->blr_aside;
-    if (aside) B7_TRY(blr_enqueue_features_aside(c, net, z));
     B7_TRY(blr_enqueue_fit(c, net, X0, Y0, N, z, alpha_prec, beta, mean, rb));
-    return blr_enqueue_score(c, net, z, spec, aside);
+    return blr_enqueue_score(c, net, z, spec);
   };
   auto redo = [&]() -> int {        // the jitter schedule of utils/math.lua:159-218, through the synchronous fit
     B7_TRY(b7_blr_fit_x(c, net, X0, Y0, N, alpha_prec, beta, mean, nullptr));

@@ -105,9 +105,6 @@ struct b7_ctx {
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
   std::vector<double> net_host;  // the basis network last uploaded to netbuf (packed W, b per layer)
-  bool blr_aside = true;          // b7_blr_eval_nominate: the candidates' features on the side stream (B7_BLR_ASIDE=0: off)
-  hipStream_t stream2 = nullptr;  // side stream: work that does not depend on the fit runs beside the fit's chain of small kernels (b7_blr_eval_nominate)
-  hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
   void *pin_eval_dev = nullptr;  // device address of pin_eval (mapped)
   void *pin_eval = nullptr;  // b7_eval_nominate: [S][4] pivot reports + [S][d] lengthscale staging (pinned)
   size_t pin_eval_bytes = 0;
