@@ -532,7 +532,7 @@ int b7_gp_set_data(b7_ctx *c, const double *X, const double *Y, int N, int d, in
   c->have_data = false;
   c->predicted = false;  // the score accumulator survives: marginalisation adds across fits (bots/bayesopt.lua:73-78)
   c->N = N;
-  c->Npad = (int)round_up(N, B7_NPAD);
+  c->Npad = npad_of(N);
   c->dfit = d;
   c->dpad = b7_dpad_class(d);
   c->ycols = ycols;
@@ -900,6 +900,11 @@ static int fit_front(b7_ctx *c, const b7_hyp *hyp, const double *ls_dev) {
 
 }  // extern "C"
 
+int npad_of(int64_t n) {
+  static const bool small_ok = [] { const char *e = getenv("B7_NPAD_SMALL"); return !(e && atoi(e) == 0); }();
+  return (small_ok && n <= 64) ? 64 : (int)round_up(n, B7_NPAD);
+}
+
 int eval_validate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec) {
   if (S < 1 || !hyps || !spec) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: S >= 1, hyps and spec required");
   if (spec->kind != B7_SCORE_EI && spec->kind != B7_SCORE_CB)
@@ -1242,7 +1247,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
   c->have_data = false;
   c->predicted = false;
   c->N = n;
-  c->Npad = (int)round_up(n, B7_NPAD);
+  c->Npad = npad_of(n);
   const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->K, nn));
   B7_TRY(b7_ensure(c, c->L, nn));
@@ -1454,7 +1459,7 @@ static int upload_net(b7_ctx *c, const b7_mlp *net, int *z_out) {
 // rows.  Everything else must be zero (the variance GEMM reads whole padded rows) and is zeroed when the buffer is
 // (re)allocated or its column layout changes -- not on every call: a 67 MB memset per nomination was a sixth of a cfg5 step.
 static int feat_alloc(b7_ctx *c, int64_t M, int z) {
-  const int zpad = (int)round_up(z, B7_NPAD);
+  const int zpad = npad_of(z);
   const size_t bytes = sizeof(double) * (size_t)round_up(M, B7_MROWS) * zpad;
   const bool grown = c->feat.cap < bytes;
   B7_TRY(b7_ensure(c, c->feat, bytes));
@@ -1475,7 +1480,7 @@ int b7_blr_basis(b7_ctx *c, const b7_mlp *net, const double *X, int64_t M, doubl
   int z = 0;
   B7_TRY(upload_net(c, net, &z));
   if (z > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
-  const int zpad = (int)round_up(z, B7_NPAD);
+  const int zpad = npad_of(z);
   if (!X) {  // resident grid -> resident features
     if (c->M <= 0 || c->d <= 0) return b7_fail(c, B7_ERR_STATE, "blr_basis: no candidate grid on this context");
     B7_TRY(feat_alloc(c, c->M, z));
@@ -1503,7 +1508,7 @@ int b7_blr_features(b7_ctx *c, const double *Z1, int64_t M, int z) {
   if (!c) return B7_ERR_INVALID;
   if (!Z1 || M < 1 || z < 1 || z > 256) return b7_fail(c, B7_ERR_INVALID, "blr_features: bad arguments");
   B7_HIP(c, hipSetDevice(c->device));
-  const int zpad = (int)round_up(z, B7_NPAD);
+  const int zpad = npad_of(z);
   B7_TRY(feat_alloc(c, M, z));
   B7_HIP(c, hipMemcpy2DAsync(c->feat.p, sizeof(double) * zpad, Z1, sizeof(double) * z, sizeof(double) * z, M,
                              hipMemcpyHostToDevice, c->stream));
@@ -1519,7 +1524,7 @@ int b7_blr_features(b7_ctx *c, const double *Z1, int64_t M, int z) {
 // Shared tail of the two fit entry points: c->tmpgrid holds Z0' (zpad x nk, zero padded) on the device.
 static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_prec, double beta, double mean,
                         double *nll_out) {
-  const int zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  const int zpad = npad_of(z), nk = (int)round_up(N, 16);
   const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
   c->have_data = false;
   c->N = z;
@@ -1583,7 +1588,7 @@ int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, doub
   B7_HIP(c, hipSetDevice(c->device));
   c->fitted = false;
   c->predicted = false;
-  const int zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  const int zpad = npad_of(z), nk = (int)round_up(N, 16);
   B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
   std::vector<double> zt((size_t)zpad * nk, 0.0);  // Z0' (a layout change, no arithmetic)
   for (int i = 0; i < N; ++i)
@@ -1605,7 +1610,7 @@ int b7_blr_fit_x(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y
   int z = 0;
   B7_TRY(upload_net(c, net, &z));
   if (z > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
-  const int d = net->dims[0], zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  const int d = net->dims[0], zpad = npad_of(z), nk = (int)round_up(N, 16);
   B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * ((size_t)N * d + (size_t)N * z)));
   B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
   double *xdev = (double *)c->tmpmu.p, *zdev = xdev + (size_t)N * d;
@@ -1649,7 +1654,7 @@ int b7_blr_predict(b7_ctx *c, double *mean_host, double *var_host) {
 // construction) redoes the fit through b7_blr_fit_x's jitter schedule and scores again.
 static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, int z, double alpha_prec,
                            double beta, double mean, std::vector<double> &rb) {
-  const int d = net->dims[0], zpad = (int)round_up(z, B7_NPAD), nk = (int)round_up(N, 16);
+  const int d = net->dims[0], zpad = npad_of(z), nk = (int)round_up(N, 16);
   const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * ((size_t)N * d + (size_t)N * z)));
   B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
@@ -1696,7 +1701,7 @@ static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const
 
 // features of the resident grid (recomputed, as models/dngo.lua:155-171 does on every predict), mean, variance, score
 static int blr_enqueue_score(b7_ctx *c, const b7_mlp *net, int z, const b7_score_spec *spec) {
-  const int zpad = (int)round_up(z, B7_NPAD);
+  const int zpad = npad_of(z);
   B7_TRY(feat_alloc(c, c->M, z));
   B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M));
   B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));

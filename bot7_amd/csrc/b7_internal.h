@@ -204,6 +204,10 @@ struct PhaseScope {
 };
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// The padded size of a system of n observations (or basis features): one 64-block up to n = 64 -- the first 64 trials of every
+// run at the reference's defaults, and the 50 features of models/dngo.lua's head: a quarter of the posterior's work and
+// half the K* bytes of the 128 padding --, multiples of 128 (the posterior kernels' n-tile) above.  B7_NPAD_SMALL=0: 128 always.
+int npad_of(int64_t n);
 
 // ---- kernel launchers (each enqueues on c->stream and returns a B7 code) ----------------------------
 // sobol.hip

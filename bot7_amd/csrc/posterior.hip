@@ -558,6 +558,78 @@ __global__ void __launch_bounds__(256)
 }
 }  // namespace w4
 
+// ---- one 64-block: N <= 64 observations (the first 64 trials of every run at the reference's defaults) or the 50 basis
+// features of the DNGO head.  L^-1 (64 x 64) stays in LDS for the workgroup's lifetime, a workgroup takes 128 candidates
+// (their K* rows staged through LDS once: 64 KB), a wave 32 of them: v = L^-1 K*' as 4 x 2 accumulator tiles, every chain over
+// k ascending up to the row tile's diagonal (what is above is zero), then per candidate the sum of squares over the 64 rows
+// in a fixed order: per lane group g the fma chain over rows 16 I + g + 4 r (I, then r, ascending), ((g0 + g1) + (g2 + g3)).
+// Nothing here depends on the grid size, the shard or the launch shape, as in the large kernels.
+namespace small64 {
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int NB = 64, LLD = NB + 2, BN = 128;
+constexpr int LDS_BYTES = (NB * LLD + BN * LLD) * 8;
+
+__global__ void __launch_bounds__(256)
+    post_small_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int64_t row0, int64_t Mtotal, double base,
+                      double sgn, double var_add, int clamp, double var_min, double *__restrict__ var, PostBatch bat) {
+  extern __shared__ __align__(16) double sm[];
+  if (bat.base) {
+    const int64_t y = blockIdx.y;
+    Linv += y * bat.sLinv;
+    ks += y * bat.sks;
+    var += y * bat.svar;
+    base = bat.base[y];
+    if (bat.var_add) var_add = bat.var_add[y];
+  }
+  double *Ls = sm, *Ks = sm + NB * LLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  // L^-1: 64 x 64, K*: 128 x 64 (rows of 512 bytes: a wave reads two whole rows per instruction)
+  for (int e = tid; e < NB * NB / 2; e += 256) {
+    const int r = e >> 5, c2 = 2 * (e & 31);
+    const d2_t v = *reinterpret_cast<const d2_t *>(Linv + (int64_t)r * NB + c2);
+    Ls[r * LLD + c2] = v[0];
+    Ls[r * LLD + c2 + 1] = v[1];
+  }
+  const double *kt = ks + ((int64_t)blockIdx.x * BN) * NB;
+  for (int e = tid; e < BN * NB / 2; e += 256) {
+    const int r = e >> 5, c2 = 2 * (e & 31);
+    const d2_t v = *reinterpret_cast<const d2_t *>(kt + (int64_t)r * NB + c2);
+    Ks[r * LLD + c2] = v[0];
+    Ks[r * LLD + c2 + 1] = v[1];
+  }
+  __syncthreads();
+  double ss[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const double *bp = Ks + (wave * 32 + j * 16 + lr) * LLD + lq;
+    double s = 0.0;
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+      const double *ap = Ls + (I * 16 + lr) * LLD + lq;
+#pragma unroll
+      for (int k4 = 0; k4 < 4 * (I + 1); ++k4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * k4], bp[4 * k4], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = __builtin_fma(c[r], c[r], s);
+    }
+    ss[j] = s;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four lane groups' sums of one candidate: (g0 + g1) + (g2 + g3)
+    double v = ss[j];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    const int64_t gidx = row0 + (int64_t)blockIdx.x * BN + wave * 32 + j * 16 + lr;
+    if (lane < 16 && gidx < Mtotal) {
+      double o = (base + sgn * v) + var_add;
+      if (clamp) o = (o < var_min) ? var_min : o;
+      var[gidx] = o;
+    }
+  }
+}
+}  // namespace small64
+
 #ifndef B7_POST_NO_LAUNCHERS
 namespace {
 struct PostArgs {  // what one launch needs besides the kernel: S fits side by side (S = 1: the context's own fit)
@@ -591,8 +663,18 @@ int launch_post_tall(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, i
   return B7_OK;
 }
 
+int launch_post_small(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(small64::post_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                small64::LDS_BYTES));
+  hipLaunchKernelGGL(small64::post_small_kernel, dim3((unsigned)(rows / small64::BN), a.S), dim3(256), small64::LDS_BYTES, c->stream,
+                     a.Linv, a.ks, row0, Mtotal, a.base, a.sgn, a.var_add, c->opts.var_clamp, c->opts.var_min, a.var, a.pb);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
 int dispatch_post(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
   if (rows % B7_MROWS) return b7_fail(c, B7_ERR_INVALID, "post: rows %lld not a multiple of %d", (long long)rows, B7_MROWS);
+  if (c->Npad == 64) return launch_post_small(c, a, row0, rows, Mtotal);
   const bool large = rows / 256 * a.S >= c->cus;  // at least one 256-candidate workgroup per CU
   // large grids: the tall shape (n-tiles of 256 rows: half the K* bytes through the L2) when the padded N allows it
   if (c->Npad % 256 == 0 && large) return launch_post_tall<2, 16>(c, a, row0, rows, Mtotal);
