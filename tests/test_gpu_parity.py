@@ -2028,3 +2028,53 @@ def test_extreme_shapes_match_oracle(ctx, orc, d, N, M):
     top2 = np.sort(acc)[-2:] if M > 1 else None
     if M == 1 or top2[1] - top2[0] > 1e-9 * max(abs(top2[1]), 1e-300):
         assert i == io
+
+
+def test_one_block_padding_appends_and_crosses_to_two_blocks(ctx, orc):
+    """N <= 64 observations live in ONE 64-block (npad_of, post_small_kernel).  Appends inside it equal the full refit; the
+    padded factor is full at 64 (refused, B7_ERR_STATE), and the model mirror's fit at N = 65 -- a rebuild in the 128
+    padding -- continues the same posterior; the same sequence with B7_NPAD_SMALL=0 (128 padding throughout) agrees to 1e-9."""
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 4, 70, 700, B.rastrigin)
+    ctx.grid_upload(X_hid)
+    ctx.gp_fit(X_obs[:58], Y[:58], **hyp)
+    for n in range(58, 64):
+        ctx.gp_append(X_obs[n], Y[n])
+        f = orc.gp.fit(X_obs[:n + 1], Y[:n + 1], **hyp)
+        L, alpha, Linv = ctx.gp_download(n + 1)
+        assert np.allclose(L, f.L, rtol=1e-9, atol=1e-12) and np.allclose(Linv @ f.L, np.eye(n + 1), atol=1e-8)
+        mu, var = ctx.gp_predict()
+        mu_o, var_o = orc.gp.predict(f, X_hid)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+    with pytest.raises(bot7_amd.Bot7HipError) as e:
+        ctx.gp_append(X_obs[64], Y[64])
+    assert e.value.code == -4
+    model = bot7_amd.models.gp_regressor({}, context=ctx)
+    model.hyp = hyp
+    seen = []
+    for n in range(62, 68):                       # the mirror extends the factor when it can and rebuilds when it must
+        out = model.predict(X_obs[:n], Y[:n], X_hid, hyp)
+        f = orc.gp.fit(X_obs[:n], Y[:n], **hyp)
+        mu_o, var_o = orc.gp.predict(f, X_hid)
+        assert relerr(out["mean"], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(out["var"], var_o) < REL
+        seen.append((np.asarray(out["mean"]).copy(), np.asarray(out["var"]).copy()))
+    # the 128 padding on a context of its own
+    os.environ["B7_NPAD_SMALL"] = "0"
+    try:
+        import subprocess
+        import sys
+        code = ("import os, sys, numpy as np; sys.path.insert(0, %r); import bot7_amd; c = bot7_amd.Context(0);"
+                "d = np.load(sys.argv[1]); c.grid_upload(d['Xh']); c.gp_fit(d['X'], d['Y'], d['ls'], float(d['amp']), float(d['noise']), float(d['mean']));"
+                "mu, var = c.gp_predict(); np.savez(sys.argv[2], mu=mu, var=var)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            np.savez(os.path.join(td, "in.npz"), X=X_obs[:63], Y=Y[:63], Xh=X_hid, ls=hyp["lenscale_sq"], amp=hyp["amp"],
+                     noise=hyp["noise"], mean=hyp["mean"])
+            out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")],
+                                 capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr[-600:]
+            ref = np.load(os.path.join(td, "out.npz"))
+            assert np.allclose(ref["mu"].ravel(), seen[1][0].ravel(), rtol=1e-9, atol=1e-12)
+            assert np.allclose(ref["var"].ravel(), seen[1][1].ravel(), rtol=1e-9, atol=1e-13)
+    finally:
+        del os.environ["B7_NPAD_SMALL"]
