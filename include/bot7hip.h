@@ -196,7 +196,7 @@ int b7_gp_fantasize(b7_ctx *ctx, const double *X_pend, int P, int nFantasies, ui
 
 /* Incremental refit (bots/abstract.lua:137-144 appends one observation per trial): extends the CURRENT fit by one
  * observation (x_new[d], y_new[ycols]) under the same hypers in O(N^2): l = L^-1 k, lambda^2 = kappa - l'l, new rows
- * of L and L^-1, alpha recomputed.  Returns B7_ERR_STATE when the padded factor is full (N a multiple of 128) or
+ * of L and L^-1, alpha recomputed.  Returns B7_ERR_STATE when the padded factor is full (N = 64, or a multiple of 128 above) or
  * lambda^2 does not stand clear of the rounding-error bound of its own evaluation,
  * lambda^2 <= (N+2) u (2 |l|'(|L^-1||k|) + l'l), u = 2^-53 (this includes lambda^2 <= 0) -- refit with b7_gp_fit then
  * (which also applies the jitter schedule). */
