@@ -570,8 +570,8 @@ constexpr int NB = 64, LLD = NB + 2, BN = 128;
 constexpr int LDS_BYTES = (NB * LLD + BN * LLD) * 8;
 
 __global__ void __launch_bounds__(256)
-    post_small_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int64_t row0, int64_t Mtotal, double base,
-                      double sgn, double var_add, int clamp, double var_min, double *__restrict__ var, PostBatch bat) {
+    post_small_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int64_t row0, int64_t Mtotal, int ntiles,
+                      double base, double sgn, double var_add, int clamp, double var_min, double *__restrict__ var, PostBatch bat) {
   extern __shared__ __align__(16) double sm[];
   if (bat.base) {
     const int64_t y = blockIdx.y;
@@ -583,49 +583,64 @@ __global__ void __launch_bounds__(256)
   }
   double *Ls = sm, *Ks = sm + NB * LLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  // L^-1: 64 x 64, K*: 128 x 64 (rows of 512 bytes: a wave reads two whole rows per instruction)
+  // a workgroup walks tiles blockIdx.x, + gridDim.x, ...: L^-1 goes to LDS once, and the K* rows of the NEXT tile are on their
+  // way (16 chunks of 16 bytes per thread, a wave reading two whole 512-byte rows per instruction) while this one is computed
+  d2_t pv[16];
+  auto fetch = [&](int tile) {
+    const double *kt = ks + ((int64_t)tile * BN) * NB;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      pv[i] = *reinterpret_cast<const d2_t *>(kt + (int64_t)(e >> 5) * NB + 2 * (e & 31));
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
   for (int e = tid; e < NB * NB / 2; e += 256) {
     const int r = e >> 5, c2 = 2 * (e & 31);
     const d2_t v = *reinterpret_cast<const d2_t *>(Linv + (int64_t)r * NB + c2);
     Ls[r * LLD + c2] = v[0];
     Ls[r * LLD + c2 + 1] = v[1];
   }
-  const double *kt = ks + ((int64_t)blockIdx.x * BN) * NB;
-  for (int e = tid; e < BN * NB / 2; e += 256) {
-    const int r = e >> 5, c2 = 2 * (e & 31);
-    const d2_t v = *reinterpret_cast<const d2_t *>(kt + (int64_t)r * NB + c2);
-    Ks[r * LLD + c2] = v[0];
-    Ks[r * LLD + c2 + 1] = v[1];
-  }
-  __syncthreads();
-  double ss[2];
+  for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const double *bp = Ks + (wave * 32 + j * 16 + lr) * LLD + lq;
-    double s = 0.0;
-#pragma unroll
-    for (int I = 0; I < 4; ++I) {
-      d4_t c = {0.0, 0.0, 0.0, 0.0};
-      const double *ap = Ls + (I * 16 + lr) * LLD + lq;
-#pragma unroll
-      for (int k4 = 0; k4 < 4 * (I + 1); ++k4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * k4], bp[4 * k4], c, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s = __builtin_fma(c[r], c[r], s);
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 5, c2 = 2 * (e & 31);
+      Ks[r * LLD + c2] = pv[i][0];
+      Ks[r * LLD + c2 + 1] = pv[i][1];
     }
-    ss[j] = s;
-  }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    double ss[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four lane groups' sums of one candidate: (g0 + g1) + (g2 + g3)
-    double v = ss[j];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    const int64_t gidx = row0 + (int64_t)blockIdx.x * BN + wave * 32 + j * 16 + lr;
-    if (lane < 16 && gidx < Mtotal) {
-      double o = (base + sgn * v) + var_add;
-      if (clamp) o = (o < var_min) ? var_min : o;
-      var[gidx] = o;
+    for (int j = 0; j < 2; ++j) {
+      const double *bp = Ks + (wave * 32 + j * 16 + lr) * LLD + lq;
+      double s = 0.0;
+#pragma unroll
+      for (int I = 0; I < 4; ++I) {
+        d4_t c = {0.0, 0.0, 0.0, 0.0};
+        const double *ap = Ls + (I * 16 + lr) * LLD + lq;
+#pragma unroll
+        for (int k4 = 0; k4 < 4 * (I + 1); ++k4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * k4], bp[4 * k4], c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = __builtin_fma(c[r], c[r], s);
+      }
+      ss[j] = s;
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four lane groups' sums of one candidate: (g0 + g1) + (g2 + g3)
+      double v = ss[j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int64_t gidx = row0 + (int64_t)tile * BN + wave * 32 + j * 16 + lr;
+      if (lane < 16 && gidx < Mtotal) {
+        double o = (base + sgn * v) + var_add;
+        if (clamp) o = (o < var_min) ? var_min : o;
+        var[gidx] = o;
+      }
+    }
+    __syncthreads();  // everybody is done with this tile's image
   }
 }
 }  // namespace small64
@@ -666,8 +681,13 @@ int launch_post_tall(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, i
 int launch_post_small(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(small64::post_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 small64::LDS_BYTES));
-  hipLaunchKernelGGL(small64::post_small_kernel, dim3((unsigned)(rows / small64::BN), a.S), dim3(256), small64::LDS_BYTES, c->stream,
-                     a.Linv, a.ks, row0, Mtotal, a.base, a.sgn, a.var_add, c->opts.var_clamp, c->opts.var_min, a.var, a.pb);
+  // one workgroup per CU holds the LDS (99 KB); with S fits side by side the CUs are split between them
+  const int ntiles = (int)(rows / small64::BN), S = a.S > 0 ? a.S : 1;
+  int gx = (c->cus + S - 1) / S;
+  if (gx > ntiles) gx = ntiles;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(small64::post_small_kernel, dim3((unsigned)gx, S), dim3(256), small64::LDS_BYTES, c->stream, a.Linv, a.ks, row0,
+                     Mtotal, ntiles, a.base, a.sgn, a.var_add, c->opts.var_clamp, c->opts.var_min, a.var, a.pb);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
