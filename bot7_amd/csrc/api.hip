@@ -854,6 +854,11 @@ int b7_gp_predict_hyp(b7_ctx *c, const b7_hyp *hyp, double *mean_host, double *v
 // away and redoes the whole nomination through the per-sample path, jitter schedule included, so the result is the
 // one the separate calls give.
 static int stage_fmin(b7_ctx *c, const double *fmin, double **fd_out) {
+  if (c->ycols == 1) {  // one response column (every path but the fantasy scores): f_min travels as a kernel argument
+    c->fmin_scalar = fmin[0];
+    *fd_out = nullptr;
+    return B7_OK;
+  }
   double *fh = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 4096);
   double *fd = (double *)((char *)c->scratch.p + 2048);
   if (!c->fmin_staged || memcmp(fh, fmin, sizeof(double) * c->ycols) != 0) {

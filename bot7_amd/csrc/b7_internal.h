@@ -92,6 +92,7 @@ struct b7_ctx {
   DevBuf var;    // M
   DevBuf acc;    // M score accumulator
   bool acc_valid = false;
+  double fmin_scalar = 0.0;  // f_min of a single response column: a kernel argument of the EI kernels (launched with fmin_dev == nullptr), no staging copy
   bool acc_fresh = false;  // the accumulator stands for zeros that were never written: the next score launch onto it starts from 0.0
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;

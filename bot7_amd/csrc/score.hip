@@ -42,13 +42,13 @@ __device__ __forceinline__ double b7_norm_pdf(double z) {
 
 __global__ void __launch_bounds__(256)
     ei_kernel(const double *__restrict__ mu, const double *__restrict__ var, const double *__restrict__ fmin,
-              double xi, int64_t M, int c, double *__restrict__ out, int accumulate) {
+              double xi, int64_t M, int c, double *__restrict__ out, int accumulate, double fmin0) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
     double sigma = sqrt(var[j]);
     double acc = 0.0;
     for (int k = 0; k < c; ++k) {
-      double imprv = (fmin[k] + (-mu[j * c + k])) + (-xi);
+      double imprv = ((fmin ? fmin[k] : fmin0) + (-mu[j * c + k])) + (-xi);  // fmin == nullptr: one column, its f_min a kernel argument
       double z = imprv / sigma;
       double ei = (imprv * b7_norm_cdf(z)) + (sigma * b7_norm_pdf(z));
       ei = (ei < 0.0) ? 0.0 : ei;
@@ -80,13 +80,13 @@ __global__ void __launch_bounds__(256)
 // what S score:add calls leave (bots/bayesopt.lua:76)
 __global__ void __launch_bounds__(256)
     ei_batch_kernel(const double *__restrict__ mu, const double *__restrict__ var, int S, int64_t sstride,
-                    const double *__restrict__ fmin, double xi, int64_t M, double *__restrict__ out, int fresh) {
+                    const double *__restrict__ fmin, double xi, int64_t M, double *__restrict__ out, int fresh, double fmin0) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
     double a = fresh ? 0.0 : out[j];  // fresh: the accumulator is torch.zeros (bots/bayesopt.lua:69), not read
     for (int s = 0; s < S; ++s) {
       double sigma = sqrt(var[s * sstride + j]);
-      double imprv = (fmin[0] + (-mu[s * sstride + j])) + (-xi);
+      double imprv = ((fmin ? fmin[0] : fmin0) + (-mu[s * sstride + j])) + (-xi);
       double z = imprv / sigma;
       double ei = (imprv * b7_norm_cdf(z)) + (sigma * b7_norm_pdf(z));
       ei = (ei < 0.0) ? 0.0 : ei;
@@ -243,8 +243,9 @@ int launch_ei(b7_ctx *c, const double *mu, const double *var, const double *fmin
               int ycols, double *out, bool accumulate) {
   PhaseScope ps(c, "score");
   if (M <= 0) return B7_OK;
+  if (!fmin_dev && ycols != 1) return b7_fail(c, B7_ERR_INVALID, "ei: f_min of %d columns must be staged on the device", ycols);
   hipLaunchKernelGGL(ei_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, fmin_dev, tradeoff, M, ycols,
-                     out, acc_mode(c, out, accumulate));
+                     out, acc_mode(c, out, accumulate), c->fmin_scalar);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
@@ -264,7 +265,7 @@ int launch_ei_batch(b7_ctx *c, int S, const double *mu, const double *var, int64
   PhaseScope ps(c, "score");
   if (M <= 0) return B7_OK;
   hipLaunchKernelGGL(ei_batch_kernel, dim3(nblocks(c, M)), dim3(256), 0, c->stream, mu, var, S, stride, fmin_dev, tradeoff, M,
-                     acc, acc_mode(c, acc, true) == 2 ? 1 : 0);
+                     acc, acc_mode(c, acc, true) == 2 ? 1 : 0, c->fmin_scalar);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
