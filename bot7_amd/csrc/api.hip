@@ -160,6 +160,7 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
+  if (const char *pv = getenv("B7_BLR_SMALL")) c->blr_small = atoi(pv) != 0;  // 0: the head of b7_blr_eval_nominate through the general launches
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
   c->persist_stamps = getenv("B7_PERSIST_STAMPS") != nullptr;
@@ -212,6 +213,7 @@ void b7_destroy(b7_ctx *c) {
   resolve_phases(c);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pin_eval) (void)hipHostFree(c->pin_eval);
+  if (c->pin_blr) (void)hipHostFree(c->pin_blr);
   if (c->pin_nll) (void)hipHostFree(c->pin_nll);
   if (c->tab_host) (void)hipHostFree(c->tab_host);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
@@ -1683,17 +1685,39 @@ static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const
   c->noise = 1.0 / beta;
   c->amp = 0.0;
   c->model_kind = 1;
-  double *xdev = (double *)c->tmpmu.p, *zdev = xdev + (size_t)N * d;
-  B7_HIP(c, hipMemcpyAsync(xdev, X0, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, c->stream));
+  // the observations and beta (y - mean) go up in ONE copy from pinned staging, laid out [X0 | beta (y - mean) | features]:
+  // the caller's arrays are pageable, and an "asynchronous" copy from pageable memory makes the host wait for the stream to
+  // reach it -- two of them per nomination serialised the host's enqueueing with the GPU's work
+  (void)rb;
+  const size_t up_doubles = (size_t)N * d + (size_t)nk;
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * (up_doubles + (size_t)N * z)));
+  if (c->pin_blr_bytes < sizeof(double) * up_doubles) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->pin_blr) (void)hipHostFree(c->pin_blr);
+    c->pin_blr = nullptr;
+    c->pin_blr_bytes = 0;
+    B7_HIP(c, hipHostMalloc(&c->pin_blr, 2 * sizeof(double) * up_doubles, hipHostMallocDefault));
+    c->pin_blr_bytes = 2 * sizeof(double) * up_doubles;
+  }
+  double *stage = static_cast<double *>(c->pin_blr);
+  memcpy(stage, X0, sizeof(double) * (size_t)N * d);
+  for (int i = 0; i < nk; ++i) stage[(size_t)N * d + i] = i < N ? beta * (Y0[i] - mean) : 0.0;
+  double *xdev = (double *)c->tmpmu.p, *yvdev = xdev + (size_t)N * d, *zdev = yvdev + nk;
+  B7_HIP(c, hipMemcpyAsync(xdev, stage, sizeof(double) * up_doubles, hipMemcpyHostToDevice, c->stream));
   B7_TRY(launch_mlp_forward(c, xdev, N, d, (const double *)c->netbuf.p, net->dims, net->n_layers, net->activation, zdev, z));
+  if (zpad == 64 && c->blr_small) {
+    // z <= 64 features: Z'Z, the assembly, b, the factorisation, its inverse and the head's weights in ONE workgroup of ONE
+    // launch (blr_small.hip) instead of nine dispatches; a failed pivot is reported and redone through b7_blr_fit_x
+    B7_TRY(launch_blr_head_small(c, zdev, N, z, z, yvdev, alpha_prec, beta, nullptr));
+    B7_HIP(c, hipMemcpyAsync(c->pinned, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
+    c->fitted = true;
+    return B7_OK;
+  }
   B7_TRY(launch_transpose_pad(c, zdev, N, z, z, (double *)c->tmpgrid.p, zpad, nk));
-  rb.assign((size_t)nk, 0.0);
-  for (int i = 0; i < N; ++i) rb[i] = beta * (Y0[i] - mean);
-  B7_HIP(c, hipMemcpyAsync(c->tmpvar.p, rb.data(), sizeof(double) * nk, hipMemcpyHostToDevice, c->stream));
   B7_TRY(launch_gemm_nt(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpgrid.p, nk, (double *)c->W.p, zpad, zpad,
                         zpad, nk));
   B7_TRY(launch_blr_assemble(c, (const double *)c->W.p, (double *)c->K.p, z, zpad, alpha_prec, beta));
-  B7_TRY(launch_gemv_rows(c, (const double *)c->tmpgrid.p, nk, (const double *)c->tmpvar.p, nk, 0.0, 0, zpad, zpad,
+  B7_TRY(launch_gemv_rows(c, (const double *)c->tmpgrid.p, nk, (const double *)yvdev, nk, 0.0, 0, zpad, zpad,
                           (double *)c->resid.p));
   B7_TRY(launch_potrf(c, 0.0, true));
   if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it

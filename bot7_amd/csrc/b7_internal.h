@@ -92,6 +92,7 @@ struct b7_ctx {
   DevBuf var;    // M
   DevBuf acc;    // M score accumulator
   bool acc_valid = false;
+  bool blr_small = true;     // b7_blr_eval_nominate: the head for z <= 64 features in one workgroup of one launch (blr_small.hip)
   double fmin_scalar = 0.0;  // f_min of a single response column: a kernel argument of the EI kernels (launched with fmin_dev == nullptr), no staging copy
   bool acc_fresh = false;  // the accumulator stands for zeros that were never written: the next score launch onto it starts from 0.0
   DevBuf ks;     // K(X*,X) chunk workspace
@@ -106,6 +107,8 @@ struct b7_ctx {
   // them directly or a copy lands without pageable staging; read after a stream synchronisation
   void *pinned = nullptr;
   std::vector<double> net_host;  // the basis network last uploaded to netbuf (packed W, b per layer)
+  void *pin_blr = nullptr;  // b7_blr_eval_nominate: pinned staging of the observations and beta (y - mean)
+  size_t pin_blr_bytes = 0;
   void *pin_eval_dev = nullptr;  // device address of pin_eval (mapped)
   void *pin_eval = nullptr;  // b7_eval_nominate: [S][4] pivot reports + [S][d] lengthscale staging (pinned)
   size_t pin_eval_bytes = 0;
@@ -266,6 +269,8 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
 size_t persist_flag_words_host(int nb);
 // nll_small.hip
 bool nll_small_applies(const b7_ctx *c);
+int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, const double *yv, double alpha_prec, double beta,
+                          int *report_dev);
 int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
                      unsigned *done_dev);
 // report_dev (nullable): device address of mapped host memory that receives the first report_words ints of the pivot report
