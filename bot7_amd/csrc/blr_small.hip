@@ -32,14 +32,32 @@ __global__ void __launch_bounds__(256)
   if (tid < 4) inf[tid] = 0;
   // the wave's tiles of G (on and below the diagonal, dealt round-robin): q = wave, wave + 4, wave + 8 (< 10)
   d4_t acc[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  double bsum = 0.0;  // thread i < 64: b_i
-  for (int n0 = 0; n0 < N; n0 += NB) {
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int r = e >> 6, cidx = e & 63, n = n0 + r;
-      Zc[r * ZLD + cidx] = (n < N && cidx < z) ? Z[(int64_t)n * ldz + cidx] : 0.0;
+  // b_i = sum_n Z[n][i] yv[n]: thread (i = tid & 63, quarter = tid >> 6) sums rows 16 quarter .. of every chunk in ascending
+  // order; the four quarters are added in order at the end
+  double bsum = 0.0;
+  // a chunk of 64 observations: sixteen elements per thread (rows (tid >> 6) + 4 i, column tid & 63), loaded from clamped
+  // addresses so that all sixteen are in flight at once, zeroed outside N x z afterwards; the NEXT chunk's loads are issued
+  // before this chunk is consumed
+  const int col = tid & 63, rq = tid >> 6, colc = col < z ? col : z - 1;
+  double pv[16], py = 0.0;
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + rq + 4 * i, nc = n < N ? n : N - 1;
+      pv[i] = Z[(int64_t)nc * ldz + colc];
     }
-    if (tid < NB) yc[tid] = (n0 + tid < N) ? yv[n0 + tid] : 0.0;
+    if (tid < NB) py = yv[(n0 + tid < N) ? n0 + tid : N - 1];
+  };
+  fetch(0);
+  for (int n0 = 0; n0 < N; n0 += NB) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = rq + 4 * i;
+      Zc[r * ZLD + col] = (n0 + r < N && col < z) ? pv[i] : 0.0;
+    }
+    if (tid < NB) yc[tid] = (n0 + tid < N) ? py : 0.0;
     __syncthreads();
+    if (n0 + NB < N) fetch(n0 + NB);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int q = wave + 4 * s;
@@ -50,8 +68,8 @@ __global__ void __launch_bounds__(256)
         for (int k4 = 0; k4 < 16; ++k4) acc[s] = mfma_f64(ap[4 * k4 * ZLD], bp[4 * k4 * ZLD], acc[s]);
       }
     }
-    if (tid < NB)
-      for (int r = 0; r < NB; ++r) bsum = __builtin_fma(Zc[r * ZLD + tid], yc[r], bsum);
+#pragma unroll
+    for (int r = 16 * rq; r < 16 * rq + 16; ++r) bsum = __builtin_fma(Zc[r * ZLD + col], yc[r], bsum);
     __syncthreads();
   }
   // A = beta G + alpha_prec I on the z x z corner, identity in the padding (blr_assemble_kernel); X = 0
@@ -75,7 +93,10 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  if (tid < NB) bv[tid] = tid < z ? bsum : 0.0;
+  tv[tid & 63] = 0.0;
+  T[tid] = bsum;  // T is free until the factor routine: the four quarters' partial sums, [quarter][i]
+  __syncthreads();
+  if (tid < NB) bv[tid] = tid < z ? ((T[tid] + T[64 + tid]) + (T[128 + tid] + T[192 + tid])) : 0.0;
   __syncthreads();
   if (tid < 256) {  // rows 0..15 x columns 48..63: I_16 (potrf_diag.h: the right-hand side of the inversion)
     const int i = tid >> 4, j = tid & 15;
