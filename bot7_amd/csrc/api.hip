@@ -160,6 +160,8 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
+  if (const char *pv = getenv("B7_POTRF_SMALL")) c->potrf_small = atoi(pv) != 0;
+  if (getenv("B7_POTRF_SCHED") || getenv("B7_DIAG_VARIANT") || getenv("B7_INVERSE_INLINE")) c->potrf_small = false;  // an explicit schedule is an A/B arm
   if (const char *pv = getenv("B7_BLR_SMALL")) c->blr_small = atoi(pv) != 0;  // 0: the head of b7_blr_eval_nominate through the general launches
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
@@ -992,15 +994,23 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
                        (double *)c->bresid.p, c->N, n, mean_dev);
     B7_TRY(launch_kxx_batch(c, S, hyp_dev, amp_dev, noise_dev, (double *)c->bw.p, (double *)c->bzsc.p, (double *)c->bzss.p,
                             (double *)c->bK.p));
+    int *reports_dev = static_cast<int *>(c->pin_eval_dev);
+    if (n == 64 && c->potrf_small) {
+      // one 64-block per fit: factorisation, inverse, alpha and the pivot report (mirrored into the mapped block) of all S fits
+      // in ONE launch of S workgroups
+      B7_TRY(launch_potrf_small(c, S, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bLinv.p, (double *)c->bdinv.p,
+                                (const double *)c->bresid.p, (double *)c->balpha.p, 0.0, (int *)c->binfo.p, reports_dev, (int64_t)nn,
+                                (int64_t)nn, (int64_t)n * B7_PANEL, (int64_t)n, 4));
+    } else {
     B7_TRY(launch_fit_batch(c, S, (const double *)c->bK.p, (double *)c->bL.p, (double *)c->bLinv.p, (double *)c->bdinv.p,
                             (unsigned *)c->bflags.p, (int *)c->binfo.p));
-    int *reports_dev = static_cast<int *>(c->pin_eval_dev);
     if (4 * S <= 256) {  // the reports ride on the last kernel of the fits into the mapped block: no copy launch
       B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p,
                                 (const int *)c->binfo.p, reports_dev, 4 * S));
     } else {
       B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p));
       B7_HIP(c, hipMemcpyAsync(reports, c->binfo.p, rep_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     }
     const size_t row_bytes = sizeof(double) * (size_t)n;
     const int64_t Mpad = round_up(c->M, B7_MROWS);
@@ -1051,7 +1061,10 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   } else {
     for (int s = 0; s < S; ++s) {
       B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
-      B7_TRY(launch_potrf(c, 0.0, true));
+      c->report_hint = static_cast<int *>(c->pin_eval_dev) + 4 * s;  // a one-block factorisation mirrors its report itself
+      const int rc_f = launch_potrf(c, 0.0, true);
+      c->report_hint = nullptr;
+      B7_TRY(rc_f);
       if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
       B7_TRY(launch_alpha(c, static_cast<int *>(c->pin_eval_dev) + 4 * s, 4));  // + this fit's pivot report, no copy launch
       c->fitted = true;
@@ -1374,6 +1387,7 @@ int b7_gp_fantasize(b7_ctx *c, const double *X_pend, int P, int n, uint64_t seed
 }
 
 int b7_gp_append(b7_ctx *c, const double *x_new, const double *y_new) {
+  if (c) c->alpha_done = false;  // whatever the last factorisation left: this call computes alpha itself
   if (!c) return B7_ERR_INVALID;
   if (!c->fitted || c->model_kind != 0) return b7_fail(c, B7_ERR_STATE, "gp_append: no GP fit on this context");
   if (!x_new || !y_new) return b7_fail(c, B7_ERR_INVALID, "gp_append: NULL argument");

@@ -92,6 +92,10 @@ struct b7_ctx {
   DevBuf var;    // M
   DevBuf acc;    // M score accumulator
   bool acc_valid = false;
+  bool potrf_small = true;   // Npad == 64: factorisation + inverse (+ alpha) in one workgroup of one launch (blr_small.hip); B7_POTRF_SMALL=0 / any explicit B7_POTRF_SCHED: off
+  bool alpha_done = false;   // the last factorisation also produced alpha (launch_alpha has nothing left to do)
+  int *report_written = nullptr; // where the last one-block factorisation did mirror it
+  int *report_hint = nullptr; // where the next factorisation should mirror its pivot report (mapped host memory), or null
   bool blr_small = true;     // b7_blr_eval_nominate: the head for z <= 64 features in one workgroup of one launch (blr_small.hip)
   double fmin_scalar = 0.0;  // f_min of a single response column: a kernel argument of the EI kernels (launched with fmin_dev == nullptr), no staging copy
   bool acc_fresh = false;  // the accumulator stands for zeros that were never written: the next score launch onto it starts from 0.0
@@ -269,6 +273,8 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
 size_t persist_flag_words_host(int nb);
 // nll_small.hip
 bool nll_small_applies(const b7_ctx *c);
+int launch_potrf_small(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, const double *resid, double *alpha,
+                       double extra, int *info, int *report_dev, int64_t sK, int64_t sL, int64_t sdinv, int64_t svec, int sinfo);
 int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, const double *yv, double alpha_prec, double beta,
                           int *report_dev);
 int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,

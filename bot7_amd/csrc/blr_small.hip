@@ -17,6 +17,7 @@
 
 namespace {
 using namespace b7diag;  // NB = 64, DLD, TLD, diag_core
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 constexpr int ZLD = NB + 1;  // row stride of a 64-observation chunk of Z in LDS
 constexpr int BLR_SMALL_LDS_DOUBLES = 2 * NB * DLD + 32 * TLD + NB * ZLD + 4 * NB;
@@ -132,6 +133,75 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ---- the GP fit's factorisation when the padded system is ONE 64-block (N <= 64) --------------------------------------
+// K (+ eps I on the real rows, utils/math.lua:190) -> L, L^-1 (= the block's dinv), pivot report, and -- with one response
+// column -- alpha = L^-T (L^-1 r) as well: the memset, the persistent launch and the three triangular matrix-vector launches of
+// the general schedule in ONE workgroup (grid.x = fit for the S hyper samples of a nomination).  The block goes through
+// b7diag::diag_core exactly as the persistent schedule's single panel does -- L and L^-1 are the same bits --; alpha is summed
+// as blr_head_small_kernel sums the head's weights.
+__global__ void __launch_bounds__(256)
+    potrf_small64_kernel(const double *__restrict__ K, double *__restrict__ L, double *__restrict__ Linv, double *__restrict__ dinv,
+                         const double *__restrict__ resid, double *__restrict__ alpha, int nreal, double extra,
+                         int *__restrict__ info, int *__restrict__ report, int64_t sK, int64_t sL, int64_t sdinv, int64_t svec,
+                         int sinfo) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ int inf[4];
+  double *A = sm, *X = A + NB * DLD, *T = X + NB * DLD, *rv = T + 32 * TLD, *tv = rv + NB;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  K += b * sK;
+  L += b * sL;
+  if (Linv) Linv += b * sL;
+  dinv += b * sdinv;
+  info += (int64_t)b * sinfo;
+  if (report) report += (int64_t)b * sinfo;
+  if (tid < 4) inf[tid] = 0;
+  for (int e = tid; e < NB * NB / 2; e += 256) {
+    const int r = e >> 5, c2 = 2 * (e & 31);
+    d2_t v = *reinterpret_cast<const d2_t *>(K + (int64_t)r * NB + c2);
+    if (r < nreal) {  // potrf_persist.hip: add_extra
+      if (c2 == r) v[0] = v[0] + extra;
+      if (c2 + 1 == r) v[1] = v[1] + extra;
+    }
+    A[r * DLD + c2] = v[0];
+    A[r * DLD + c2 + 1] = v[1];
+  }
+  for (int e = tid; e < NB * DLD; e += 256) X[e] = 0.0;
+  if (resid && tid < NB) rv[tid] = resid[b * svec + tid];
+  __syncthreads();
+  {
+    const int i = tid >> 4, j = tid & 15;
+    A[i * DLD + 48 + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  diag_core<1, false>(A, X, T, 0, inf, nullptr);
+  if (resid) {
+    const int row = tid >> 2, part = tid & 3;
+    double a = 0.0;
+    for (int k = 16 * part; k < 16 * part + 16; ++k) a = __builtin_fma(X[row * DLD + k], rv[k], a);
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (part == 0) tv[row] = a;
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    const double x = j <= i ? X[i * DLD + j] : 0.0;
+    L[e] = j <= i ? A[i * DLD + j] : 0.0;
+    if (Linv) Linv[e] = x;
+    dinv[e] = x;
+  }
+  __syncthreads();
+  if (resid && tid < NB) {
+    double a = 0.0;
+    for (int i = tid; i < NB; ++i) a = __builtin_fma(X[i * DLD + tid], tv[i], a);
+    alpha[b * svec + tid] = tid < nreal ? a : 0.0;
+  }
+  if (tid < 4) {
+    info[tid] = inf[tid];
+    if (report) report[tid] = inf[tid];
+  }
+}
+
 }  // namespace
 
 // Z: N x z features of the observations (row stride ldz), yv[N] = beta (y - mean), both on the device.  Writes L, L^-1
@@ -151,5 +221,23 @@ int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, con
                      (double *)c->Linv.p, (double *)c->alpha.p, (double *)c->resid.p, (int *)c->info.p, report_dev);
   B7_HIP(c, hipGetLastError());
   c->linv_done = true;
+  return B7_OK;
+}
+
+// B fits whose padded system is one 64-block: K_b -> L_b, Linv_b (nullable), dinv_b, info_b (+ a copy in mapped host memory
+// when report_dev is given) and, when resid is given (one response column), alpha_b.  Strides in doubles / ints.
+int launch_potrf_small(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, const double *resid, double *alpha,
+                       double extra, int *info, int *report_dev, int64_t sK, int64_t sL, int64_t sdinv, int64_t svec, int sinfo) {
+  PhaseScope ps(c, "potrf");
+  if (c->Npad != NB) return b7_fail(c, B7_ERR_INVALID, "potrf_small: padded size %d", c->Npad);
+  const size_t lds = sizeof(double) * (2 * NB * DLD + 32 * TLD + 2 * NB);
+  static bool attr_done[64] = {false};
+  if (c->device >= 64 || !attr_done[c->device]) {
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_small64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->device < 64) attr_done[c->device] = true;
+  }
+  hipLaunchKernelGGL(potrf_small64_kernel, dim3(B), dim3(256), lds, c->stream, K, L, Linv, dinv, resid, alpha, c->N, extra, info,
+                     report_dev, sK, sL, sdinv, svec, sinfo);
+  B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
