@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256)
 namespace small64 {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int NB = 64, LLD = NB + 2, BN = 128;
-constexpr int LDS_BYTES = (NB * LLD + BN * LLD) * 8;
+constexpr int LDS_BYTES = BN * LLD * 8;  // the K* tile; L^-1 lives in registers
 
 __global__ void __launch_bounds__(256)
     post_small_kernel(const double *__restrict__ Linv, const double *__restrict__ ks, int64_t row0, int64_t Mtotal, int ntiles,
@@ -581,10 +581,10 @@ __global__ void __launch_bounds__(256)
     base = bat.base[y];
     if (bat.var_add) var_add = bat.var_add[y];
   }
-  double *Ls = sm, *Ks = sm + NB * LLD;
+  double *Ks = sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  // a workgroup walks tiles blockIdx.x, + gridDim.x, ...: L^-1 goes to LDS once, and the K* rows of the NEXT tile are on their
-  // way (16 chunks of 16 bytes per thread, a wave reading two whole 512-byte rows per instruction) while this one is computed
+  // a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the K* rows of the NEXT tile are on their way (16 chunks of 16 bytes
+  // per thread, a wave reading two whole 512-byte rows per instruction) while this one is computed
   d2_t pv[16];
   auto fetch = [&](int tile) {
     const double *kt = ks + ((int64_t)tile * BN) * NB;
@@ -596,12 +596,14 @@ __global__ void __launch_bounds__(256)
   };
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
-  for (int e = tid; e < NB * NB / 2; e += 256) {
-    const int r = e >> 5, c2 = 2 * (e & 31);
-    const d2_t v = *reinterpret_cast<const d2_t *>(Linv + (int64_t)r * NB + c2);
-    Ls[r * LLD + c2] = v[0];
-    Ls[r * LLD + c2 + 1] = v[1];
-  }
+  // L^-1 is the same for every tile: its A fragments -- row tile I, k-steps 0 .. 4 I + 3 (nothing above the diagonal) -- are
+  // read from memory ONCE into 40 registers per lane; per tile only the candidates' fragments come from LDS, sixteen per
+  // candidate strip, and the MFMA chains run from registers
+  double af[40];
+#pragma unroll
+  for (int I = 0; I < 4; ++I)
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (I + 1); ++k4) af[2 * I * (I + 1) + k4] = Linv[(int64_t)(I * 16 + lr) * NB + 4 * k4 + lq];
   for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -615,13 +617,15 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const double *bp = Ks + (wave * 32 + j * 16 + lr) * LLD + lq;
+      double bf[16];
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4) bf[k4] = bp[4 * k4];
       double s = 0.0;
 #pragma unroll
       for (int I = 0; I < 4; ++I) {
         d4_t c = {0.0, 0.0, 0.0, 0.0};
-        const double *ap = Ls + (I * 16 + lr) * LLD + lq;
 #pragma unroll
-        for (int k4 = 0; k4 < 4 * (I + 1); ++k4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * k4], bp[4 * k4], c, 0, 0, 0);
+        for (int k4 = 0; k4 < 4 * (I + 1); ++k4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(af[2 * I * (I + 1) + k4], bf[k4], c, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s = __builtin_fma(c[r], c[r], s);
       }
@@ -681,9 +685,9 @@ int launch_post_tall(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, i
 int launch_post_small(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(small64::post_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 small64::LDS_BYTES));
-  // one workgroup per CU holds the LDS (99 KB); with S fits side by side the CUs are split between them
+  // two workgroups per CU fit (66 KB of LDS each); with S fits side by side the CUs are split between them
   const int ntiles = (int)(rows / small64::BN), S = a.S > 0 ? a.S : 1;
-  int gx = (c->cus + S - 1) / S;
+  int gx = (2 * c->cus + S - 1) / S;
   if (gx > ntiles) gx = ntiles;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(small64::post_small_kernel, dim3((unsigned)gx, S), dim3(256), small64::LDS_BYTES, c->stream, a.Linv, a.ks, row0,
