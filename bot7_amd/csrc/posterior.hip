@@ -604,6 +604,15 @@ __global__ void __launch_bounds__(256)
   for (int I = 0; I < 4; ++I)
 #pragma unroll
     for (int k4 = 0; k4 < 4 * (I + 1); ++k4) af[2 * I * (I + 1) + k4] = Linv[(int64_t)(I * 16 + lr) * NB + 4 * k4 + lq];
+  // every load so far has landed before the loop is entered: with the 40 fragment loads still counted as outstanding at the
+  // loop head, the compiler's (counter-based) waits for them sit in the middle of the MFMA section and, from the second
+  // iteration on, wait for the PREFETCH instead -- load and compute times added up (41 us for 1564 tiles) instead of overlapping
+  // (as empty asm statements that "use" the fragments: a plain s_waitcnt does not keep the optimiser from sinking the loads
+  // below it, and only a wait the compiler inserted itself clears its bookkeeping)
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    asm volatile("" : "+v"(af[10 * g]), "+v"(af[10 * g + 1]), "+v"(af[10 * g + 2]), "+v"(af[10 * g + 3]), "+v"(af[10 * g + 4]),
+                      "+v"(af[10 * g + 5]), "+v"(af[10 * g + 6]), "+v"(af[10 * g + 7]), "+v"(af[10 * g + 8]), "+v"(af[10 * g + 9]));
   for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -613,6 +622,8 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE: left to itself the scheduler sinks them below the MFMA section
+                                        // to shorten 64 registers' live range, and load and compute times add instead of overlapping
     double ss[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -624,8 +635,12 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int I = 0; I < 4; ++I) {
         d4_t c = {0.0, 0.0, 0.0, 0.0};
+#ifdef B7_PS_ABLATE  // diagnostic build only (never defined for the shipped library): one MFMA per chain instead of 4 (I + 1)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(af[2 * I * (I + 1)], bf[I], c, 0, 0, 0);
+#else
 #pragma unroll
         for (int k4 = 0; k4 < 4 * (I + 1); ++k4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(af[2 * I * (I + 1) + k4], bf[k4], c, 0, 0, 0);
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) s = __builtin_fma(c[r], c[r], s);
       }
