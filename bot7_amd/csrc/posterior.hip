@@ -559,14 +559,15 @@ __global__ void __launch_bounds__(256)
 }  // namespace w4
 
 // ---- one 64-block: N <= 64 observations (the first 64 trials of every run at the reference's defaults) or the 50 basis
-// features of the DNGO head.  L^-1 (64 x 64) stays in LDS for the workgroup's lifetime, a workgroup takes 128 candidates
-// (their K* rows staged through LDS once: 64 KB), a wave 32 of them: v = L^-1 K*' as 4 x 2 accumulator tiles, every chain over
-// k ascending up to the row tile's diagonal (what is above is zero), then per candidate the sum of squares over the 64 rows
-// in a fixed order: per lane group g the fma chain over rows 16 I + g + 4 r (I, then r, ascending), ((g0 + g1) + (g2 + g3)).
+// features of the DNGO head.  A persistent workgroup (two per CU) reads the A fragments of L^-1 (64 x 64) into registers once
+// and walks tiles of 64 candidates -- their K* rows staged through LDS, the next tile's in flight meanwhile --, a wave 16 of
+// them: v = L^-1 K*' as four accumulator tiles, every chain over k ascending up to the row tile's diagonal (what is above is
+// zero), then per candidate the sum of squares over the 64 rows in a fixed order: per lane group g the fma chain over rows
+// 16 I + g + 4 r (I, then r, ascending), ((g0 + g1) + (g2 + g3)).
 // Nothing here depends on the grid size, the shard or the launch shape, as in the large kernels.
 namespace small64 {
 typedef double d4_t __attribute__((ext_vector_type(4)));
-constexpr int NB = 64, LLD = NB + 2, BN = 128;
+constexpr int NB = 64, LLD = NB + 2, BN = 64;  // 64 candidates per tile: ~200 registers, two workgroups per CU -- one loads while the other computes
 constexpr int LDS_BYTES = BN * LLD * 8;  // the K* tile; L^-1 lives in registers
 
 __global__ void __launch_bounds__(256)
@@ -585,11 +586,11 @@ __global__ void __launch_bounds__(256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   // a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the K* rows of the NEXT tile are on their way (16 chunks of 16 bytes
   // per thread, a wave reading two whole 512-byte rows per instruction) while this one is computed
-  d2_t pv[16];
+  d2_t pv[BN / 8];
   auto fetch = [&](int tile) {
     const double *kt = ks + ((int64_t)tile * BN) * NB;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < BN / 8; ++i) {
       const int e = tid + 256 * i;
       pv[i] = *reinterpret_cast<const d2_t *>(kt + (int64_t)(e >> 5) * NB + 2 * (e & 31));
     }
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(256)
                       "+v"(af[10 * g + 5]), "+v"(af[10 * g + 6]), "+v"(af[10 * g + 7]), "+v"(af[10 * g + 8]), "+v"(af[10 * g + 9]));
   for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < BN / 8; ++i) {
       const int e = tid + 256 * i, r = e >> 5, c2 = 2 * (e & 31);
       Ks[r * LLD + c2] = pv[i][0];
       Ks[r * LLD + c2 + 1] = pv[i][1];
@@ -624,10 +625,11 @@ __global__ void __launch_bounds__(256)
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
     __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE: left to itself the scheduler sinks them below the MFMA section
                                         // to shorten 64 registers' live range, and load and compute times add instead of overlapping
-    double ss[2];
+    constexpr int NJ = BN / 64;  // 16-candidate strips per wave
+    double ss[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const double *bp = Ks + (wave * 32 + j * 16 + lr) * LLD + lq;
+    for (int j = 0; j < NJ; ++j) {
+      const double *bp = Ks + (wave * 16 * NJ + j * 16 + lr) * LLD + lq;
       double bf[16];
 #pragma unroll
       for (int k4 = 0; k4 < 16; ++k4) bf[k4] = bp[4 * k4];
@@ -647,12 +649,12 @@ __global__ void __launch_bounds__(256)
       ss[j] = s;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four lane groups' sums of one candidate: (g0 + g1) + (g2 + g3)
       double v = ss[j];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      const int64_t gidx = row0 + (int64_t)tile * BN + wave * 32 + j * 16 + lr;
+      const int64_t gidx = row0 + (int64_t)tile * BN + wave * 16 * NJ + j * 16 + lr;
       if (lane < 16 && gidx < Mtotal) {
         double o = (base + sgn * v) + var_add;
         if (clamp) o = (o < var_min) ? var_min : o;
@@ -700,7 +702,7 @@ int launch_post_tall(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, i
 int launch_post_small(b7_ctx *c, const PostArgs &a, int64_t row0, int64_t rows, int64_t Mtotal) {
   B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(small64::post_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 small64::LDS_BYTES));
-  // two workgroups per CU fit (66 KB of LDS each); with S fits side by side the CUs are split between them
+  // two workgroups per CU (33 KB of LDS, ~200 registers each); with S fits side by side the CUs are split between them
   const int ntiles = (int)(rows / small64::BN), S = a.S > 0 ? a.S : 1;
   int gx = (2 * c->cus + S - 1) / S;
   if (gx > ntiles) gx = ntiles;
