@@ -58,6 +58,7 @@ class Mlp(C.Structure):
 
 
 ACTIVATIONS = {None: 0, "Identity": 0, "Tanh": 1, "ReLU": 2, "Sigmoid": 3}
+_MLP_CACHE = {}
 
 
 class GpOpts(C.Structure):
@@ -467,12 +468,22 @@ class Context(object):
     def _mlp(weights, biases, activation):
         Ws = [_f64(w) for w in weights]
         bs = [_f64(b).ravel() for b in biases]
+        # the same arrays as last time (a trial loop hands the same network to every call until it retrains it): the ctypes
+        # description is reused -- it only holds pointers, the library reads the weights themselves on every call
+        key = (activation,) + tuple((w.__array_interface__["data"][0], w.shape) for w in Ws) + tuple(
+            (b.__array_interface__["data"][0], b.shape) for b in bs)
+        hit = _MLP_CACHE.get(key)
+        if hit is not None:
+            return hit
         n = len(Ws)
         dims = (C.c_int * (n + 1))(*([Ws[0].shape[1]] + [w.shape[0] for w in Ws]))
         Wp = (C.POINTER(C.c_double) * n)(*[w.ctypes.data_as(C.POINTER(C.c_double)) for w in Ws])
         bp = (C.POINTER(C.c_double) * n)(*[b.ctypes.data_as(C.POINTER(C.c_double)) for b in bs])
         m = Mlp(n, dims, Wp, bp, ACTIVATIONS[activation])
-        m._keep = (Ws, bs, dims, Wp, bp)
+        m._keep = (Ws, bs, dims, Wp, bp)      # the arrays stay alive as long as the description does
+        if len(_MLP_CACHE) >= 8:
+            _MLP_CACHE.clear()
+        _MLP_CACHE[key] = m
         return m
 
     def blr_basis(self, weights, biases, activation="Tanh", X=None, download=False):
