@@ -160,6 +160,7 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
+  if (const char *pv = getenv("B7_NPAD_SMALL")) c->npad_small = atoi(pv) != 0;  // 0: pad N <= 64 (and <= 64 basis features) to 128 as N > 64
   if (const char *pv = getenv("B7_POTRF_SMALL")) c->potrf_small = atoi(pv) != 0;
   if (getenv("B7_POTRF_SCHED") || getenv("B7_DIAG_VARIANT") || getenv("B7_INVERSE_INLINE")) c->potrf_small = false;  // an explicit schedule is an A/B arm
   if (const char *pv = getenv("B7_BLR_SMALL")) c->blr_small = atoi(pv) != 0;  // 0: the head of b7_blr_eval_nominate through the general launches
@@ -536,7 +537,7 @@ int b7_gp_set_data(b7_ctx *c, const double *X, const double *Y, int N, int d, in
   c->have_data = false;
   c->predicted = false;  // the score accumulator survives: marginalisation adds across fits (bots/bayesopt.lua:73-78)
   c->N = N;
-  c->Npad = npad_of(N);
+  c->Npad = npad_of(c, N);
   c->dfit = d;
   c->dpad = b7_dpad_class(d);
   c->ycols = ycols;
@@ -909,10 +910,7 @@ static int fit_front(b7_ctx *c, const b7_hyp *hyp, const double *ls_dev) {
 
 }  // extern "C"
 
-int npad_of(int64_t n) {
-  static const bool small_ok = [] { const char *e = getenv("B7_NPAD_SMALL"); return !(e && atoi(e) == 0); }();
-  return (small_ok && n <= 64) ? 64 : (int)round_up(n, B7_NPAD);
-}
+int npad_of(const b7_ctx *c, int64_t n) { return (c->npad_small && n <= 64) ? 64 : (int)round_up(n, B7_NPAD); }
 
 int eval_validate(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec) {
   if (S < 1 || !hyps || !spec) return b7_fail(c, B7_ERR_INVALID, "eval_nominate: S >= 1, hyps and spec required");
@@ -1267,7 +1265,7 @@ int b7_chol(b7_ctx *c, const double *src, int n, double *res, double *jitter_use
   c->have_data = false;
   c->predicted = false;
   c->N = n;
-  c->Npad = npad_of(n);
+  c->Npad = npad_of(c, n);
   const size_t np = (size_t)c->Npad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->K, nn));
   B7_TRY(b7_ensure(c, c->L, nn));
@@ -1480,7 +1478,7 @@ static int upload_net(b7_ctx *c, const b7_mlp *net, int *z_out) {
 // rows.  Everything else must be zero (the variance GEMM reads whole padded rows) and is zeroed when the buffer is
 // (re)allocated or its column layout changes -- not on every call: a 67 MB memset per nomination was a sixth of a cfg5 step.
 static int feat_alloc(b7_ctx *c, int64_t M, int z) {
-  const int zpad = npad_of(z);
+  const int zpad = npad_of(c, z);
   const size_t bytes = sizeof(double) * (size_t)round_up(M, B7_MROWS) * zpad;
   const bool grown = c->feat.cap < bytes;
   B7_TRY(b7_ensure(c, c->feat, bytes));
@@ -1501,7 +1499,7 @@ int b7_blr_basis(b7_ctx *c, const b7_mlp *net, const double *X, int64_t M, doubl
   int z = 0;
   B7_TRY(upload_net(c, net, &z));
   if (z > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
-  const int zpad = npad_of(z);
+  const int zpad = npad_of(c, z);
   if (!X) {  // resident grid -> resident features
     if (c->M <= 0 || c->d <= 0) return b7_fail(c, B7_ERR_STATE, "blr_basis: no candidate grid on this context");
     B7_TRY(feat_alloc(c, c->M, z));
@@ -1529,7 +1527,7 @@ int b7_blr_features(b7_ctx *c, const double *Z1, int64_t M, int z) {
   if (!c) return B7_ERR_INVALID;
   if (!Z1 || M < 1 || z < 1 || z > 256) return b7_fail(c, B7_ERR_INVALID, "blr_features: bad arguments");
   B7_HIP(c, hipSetDevice(c->device));
-  const int zpad = npad_of(z);
+  const int zpad = npad_of(c, z);
   B7_TRY(feat_alloc(c, M, z));
   B7_HIP(c, hipMemcpy2DAsync(c->feat.p, sizeof(double) * zpad, Z1, sizeof(double) * z, sizeof(double) * z, M,
                              hipMemcpyHostToDevice, c->stream));
@@ -1545,7 +1543,7 @@ int b7_blr_features(b7_ctx *c, const double *Z1, int64_t M, int z) {
 // Shared tail of the two fit entry points: c->tmpgrid holds Z0' (zpad x nk, zero padded) on the device.
 static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_prec, double beta, double mean,
                         double *nll_out) {
-  const int zpad = npad_of(z), nk = (int)round_up(N, 16);
+  const int zpad = npad_of(c, z), nk = (int)round_up(N, 16);
   const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
   c->have_data = false;
   c->N = z;
@@ -1609,7 +1607,7 @@ int b7_blr_fit(b7_ctx *c, const double *Z0, const double *Y0, int N, int z, doub
   B7_HIP(c, hipSetDevice(c->device));
   c->fitted = false;
   c->predicted = false;
-  const int zpad = npad_of(z), nk = (int)round_up(N, 16);
+  const int zpad = npad_of(c, z), nk = (int)round_up(N, 16);
   B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
   std::vector<double> zt((size_t)zpad * nk, 0.0);  // Z0' (a layout change, no arithmetic)
   for (int i = 0; i < N; ++i)
@@ -1631,7 +1629,7 @@ int b7_blr_fit_x(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y
   int z = 0;
   B7_TRY(upload_net(c, net, &z));
   if (z > 256) return b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
-  const int d = net->dims[0], zpad = npad_of(z), nk = (int)round_up(N, 16);
+  const int d = net->dims[0], zpad = npad_of(c, z), nk = (int)round_up(N, 16);
   B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * ((size_t)N * d + (size_t)N * z)));
   B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
   double *xdev = (double *)c->tmpmu.p, *zdev = xdev + (size_t)N * d;
@@ -1675,7 +1673,7 @@ int b7_blr_predict(b7_ctx *c, double *mean_host, double *var_host) {
 // construction) redoes the fit through b7_blr_fit_x's jitter schedule and scores again.
 static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, int z, double alpha_prec,
                            double beta, double mean, std::vector<double> &rb) {
-  const int d = net->dims[0], zpad = npad_of(z), nk = (int)round_up(N, 16);
+  const int d = net->dims[0], zpad = npad_of(c, z), nk = (int)round_up(N, 16);
   const size_t np = (size_t)zpad, nn = np * np * sizeof(double);
   B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * ((size_t)N * d + (size_t)N * z)));
   B7_TRY(b7_ensure(c, c->tmpgrid, sizeof(double) * (size_t)zpad * nk));
@@ -1744,7 +1742,7 @@ static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const
 
 // features of the resident grid (recomputed, as models/dngo.lua:155-171 does on every predict), mean, variance, score
 static int blr_enqueue_score(b7_ctx *c, const b7_mlp *net, int z, const b7_score_spec *spec) {
-  const int zpad = npad_of(z);
+  const int zpad = npad_of(c, z);
   B7_TRY(feat_alloc(c, c->M, z));
   B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M));
   B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));

@@ -92,6 +92,7 @@ struct b7_ctx {
   DevBuf var;    // M
   DevBuf acc;    // M score accumulator
   bool acc_valid = false;
+  bool npad_small = true;    // N <= 64 (and <= 64 basis features) padded to ONE 64-block (B7_NPAD_SMALL=0: to 128)
   bool potrf_small = true;   // Npad == 64: factorisation + inverse (+ alpha) in one workgroup of one launch (blr_small.hip); B7_POTRF_SMALL=0 / any explicit B7_POTRF_SCHED: off
   bool alpha_done = false;   // the last factorisation also produced alpha (launch_alpha has nothing left to do)
   int *report_written = nullptr; // where the last one-block factorisation did mirror it
@@ -214,8 +215,9 @@ struct PhaseScope {
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 // The padded size of a system of n observations (or basis features): one 64-block up to n = 64 -- the first 64 trials of every
 // run at the reference's defaults, and the 50 features of models/dngo.lua's head: a quarter of the posterior's work and
-// half the K* bytes of the 128 padding --, multiples of 128 (the posterior kernels' n-tile) above.  B7_NPAD_SMALL=0: 128 always.
-int npad_of(int64_t n);
+// half the K* bytes of the 128 padding --, multiples of 128 (the posterior kernels' n-tile) above.  B7_NPAD_SMALL=0 (read in
+// b7_create, like every switch): 128 always.
+int npad_of(const b7_ctx *c, int64_t n);
 
 // ---- kernel launchers (each enqueues on c->stream and returns a B7 code) ----------------------------
 // sobol.hip
