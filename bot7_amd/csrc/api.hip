@@ -160,6 +160,7 @@ int b7_create(b7_ctx **out, int device_id) {
   b7_gp_default_opts(&c->opts);
   // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
+  if (const char *pv = getenv("B7_SPIN_US")) c->spin_us = atoi(pv);  // 0: never spin on a completion word, always wait for the stream
   if (const char *pv = getenv("B7_NPAD_SMALL")) c->npad_small = atoi(pv) != 0;  // 0: pad N <= 64 (and <= 64 basis features) to 128 as N > 64
   if (const char *pv = getenv("B7_POTRF_SMALL")) c->potrf_small = atoi(pv) != 0;
   if (getenv("B7_POTRF_SCHED") || getenv("B7_DIAG_VARIANT") || getenv("B7_INVERSE_INLINE")) c->potrf_small = false;  // an explicit schedule is an A/B arm
@@ -704,9 +705,9 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     bool answered = false;
     if (B == 1) {
       const auto t0 = std::chrono::steady_clock::now();
-      for (unsigned spins = 0; !answered; ++spins) {
+      for (unsigned spins = 0; !answered && c->spin_us > 0; ++spins) {
         answered = __atomic_load_n(const_cast<const unsigned *>(done), __ATOMIC_ACQUIRE) != 0u;
-        if (!answered && (spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        if (!answered && (spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->spin_us < 200 ? c->spin_us : 200)) break;
       }
     }
     if (!answered) B7_HIP(c, hipStreamSynchronize(c->stream));

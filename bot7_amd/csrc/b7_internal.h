@@ -92,6 +92,7 @@ struct b7_ctx {
   DevBuf var;    // M
   DevBuf acc;    // M score accumulator
   bool acc_valid = false;
+  int spin_us = 500;         // how long a call spins on a completion word in mapped host memory before it waits for the stream (B7_SPIN_US; 0: never)
   bool npad_small = true;    // N <= 64 (and <= 64 basis features) padded to ONE 64-block (B7_NPAD_SMALL=0: to 128)
   bool potrf_small = true;   // Npad == 64: factorisation + inverse (+ alpha) in one workgroup of one launch (blr_small.hip); B7_POTRF_SMALL=0 / any explicit B7_POTRF_SCHED: off
   bool alpha_done = false;   // the last factorisation also produced alpha (launch_alpha has nothing left to do)

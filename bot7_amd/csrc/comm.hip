@@ -97,9 +97,9 @@ int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, b
 int exch_wait_mirror(b7_ctx *c) {
   volatile unsigned *done = mirror_done_word(c);
   const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0;; ++spins) {
+  for (unsigned spins = 0; c->spin_us > 0; ++spins) {
     if (__atomic_load_n(const_cast<const unsigned *>(done), __ATOMIC_ACQUIRE) != 0u) return B7_OK;
-    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->spin_us)) break;
   }
   B7_HIP(c, hipStreamSynchronize(c->stream));
   if (__atomic_load_n(const_cast<const unsigned *>(done), __ATOMIC_ACQUIRE) == 0u)

@@ -2078,3 +2078,25 @@ def test_one_block_padding_appends_and_crosses_to_two_blocks(ctx, orc):
             assert np.allclose(ref["var"].ravel(), seen[1][1].ravel(), rtol=1e-9, atol=1e-13)
     finally:
         del os.environ["B7_NPAD_SMALL"]
+
+
+def test_completion_word_and_stream_wait_give_the_same_answers(ctx, orc):
+    """b7_eval_nominate and a single b7_gp_nll_batch evaluation are answered through a word the last kernel raises in mapped host
+    memory; B7_SPIN_US=0 makes the same calls wait for the stream instead (the fallback a slow answer takes): same bits."""
+    import bot7_amd
+    X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 3, 40, 900, B.rastrigin)
+    os.environ["B7_SPIN_US"] = "0"
+    try:
+        slow = bot7_amd.Context(0)
+    finally:
+        del os.environ["B7_SPIN_US"]
+    got = []
+    for c in (ctx, slow):
+        c.grid_upload(X_hid)
+        c.gp_set_data(X_obs, Y)
+        hyps = [dict(hyp, lenscale_sq=hyp["lenscale_sq"] * (1 + 0.1 * s)) for s in range(3)]
+        r = [c.eval_nominate(hyps[:S], score="ei", fmin=[float(Y.min())]) for S in (1, 3)]
+        r.append(c.gp_nll_batch(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"]).tobytes())
+        c.score_reset()
+        got.append(r)
+    assert got[0] == got[1]
