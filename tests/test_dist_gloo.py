@@ -68,63 +68,12 @@ def test_sharded_argmax_exchange_gloo(world):
         assert all(out), "rank %d disagreed with the unsharded arg-max: %s" % (rank, out)
 
 
-class _OracleCtx(object):
-    """Stands in for bot7_amd.Context on a machine without a GPU: the calls ShardedScorer.eval_nominate makes on its gloo
-    path, answered by the oracle over this rank's rows."""
-
-    def __init__(self, X_obs, Y, X_shard):
-        from oracle import cport, gp
-        self.c, self.gp, self.X_obs, self.Y, self.X = cport, gp, X_obs, Y, X_shard
-        self.acc = None
-
-    def comm_info(self):
-        return (0, 1)                      # no communicator: the torch.distributed exchange is used
-
-    # -- what the harness bot's trial loop calls besides (tests/test_sharded_loop.py)
-    def gp_set_data(self, X_obs, Y):
-        self.X_obs, self.Y = np.asarray(X_obs, dtype=np.float64), np.asarray(Y, dtype=np.float64)
-
-    def grid_shape(self):
-        return self.X.shape
-
-    def grid_remove(self, idx1):           # utils.tensor.remove (utils/tensor.lua:158-170): stable deletion
-        row = self.X[idx1 - 1].copy()
-        self.X = np.delete(self.X, idx1 - 1, axis=0)
-        return row
-
-    def eval_nominate(self, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0, global_row_offset=0):
-        """The unsharded nomination (a world of one): bots/bayesopt.lua:56-99 with the oracle."""
-        for s, h in enumerate(hyps):
-            self.gp_predict_hyp(h["lenscale_sq"], h["amp"], h["noise"], h["mean"])
-            if s == 0:
-                self.score_reset()
-            if score == "ei":
-                self.score_ei(fmin, tradeoff or 0.0)
-            else:
-                self.score_cb(1.0 if tradeoff is None else tradeoff, upper, sign)
-        v, i, _ = self.score_finish(float(len(hyps)))
-        return v, global_row_offset + i
-
-    def nominate_commit(self, idx1_global, lo):
-        return self.grid_remove(idx1_global - lo), lo
-
-    def gp_predict_hyp(self, lenscale_sq, amp, noise, mean):
-        f = self.gp.fit(self.X_obs, self.Y, lenscale_sq, amp, noise, mean)
-        self.mu, self.var = self.gp.predict(f, self.X)
-
-    def score_reset(self):
-        self.acc = np.zeros(self.X.shape[0])
-
-    def score_ei(self, fmin, tradeoff):
-        self.c.accumulate(self.acc, self.c.ei(self.mu, self.var, fmin, tradeoff))
-
-    def score_cb(self, tradeoff, upper, sign):
-        self.c.accumulate(self.acc, self.c.cb(self.mu, self.var, tradeoff, upper, sign))
-
-    def score_finish(self, divisor, download=False):
-        self.c.divide(self.acc, divisor)
-        i, v = self.c.argmax_first(self.acc)
-        return v, i, None
+def _OracleCtx(X_obs, Y, X_shard):
+    """The device's stand-in on a machine without a GPU: oracle/hostctx.py (the calls ShardedScorer and the harness bot make on a
+    Context, answered by the oracle over this rank's rows)."""
+    sys.path.insert(0, ROOT)
+    from oracle.hostctx import OracleContext
+    return OracleContext(X_obs, Y, X_shard)
 
 
 def _nominate_worker(rank, world, port, q):
