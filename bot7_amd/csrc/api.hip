@@ -170,7 +170,8 @@ int b7_create(b7_ctx **out, int device_id) {
   c->persist_stamps = getenv("B7_PERSIST_STAMPS") != nullptr;
   if (const char *pv = getenv("B7_PERSIST_HELPERS")) c->persist_helpers = atoi(pv);
   if (const char *pv = getenv("B7_PERSIST_FAULT")) c->persist_fault = atoi(pv);
-  if (const char *pv = getenv("B7_NLL_SMALL")) c->nll_small = atoi(pv) != 0;  // 0: likelihoods of small sets through the general path too
+  if (const char *pv = getenv("B7_NLL_SMALL")) c->nll_small = atoi(pv);  // 0: likelihoods of small sets through the general path too; 2: round 3's kernel
+  if (const char *pv = getenv("B7_FIT_SMALL")) c->fit_small = atoi(pv) != 0;  // 0: small fits through the general schedule too
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
@@ -584,8 +585,23 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
   double *ls_stage = reinterpret_cast<double *>(static_cast<char *>(c->pinned) + 8192);
   double *ls_dev = (double *)c->scratch.p;  // first 4096 bytes of scratch: up to 512 doubles
   memcpy(ls_stage, hyp->lenscale_sq, sizeof(double) * d);
-  B7_HIP(c, hipMemcpyAsync(ls_dev, ls_stage, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
-  B7_TRY(fit_front(c, hyp, ls_dev));
+  // N <= 128, d <= 32, one response column: residual, observation scaling, K(X,X), factorisation, inverse and alpha are ONE
+  // workgroup of ONE launch (gp_small.hip) with the d + 3 hypers in the kernel arguments; the kernel also leaves the
+  // lengthscales where b7_gp_append / b7_gp_fantasize look for the current fit's.  K itself is not kept: a failed pivot
+  // (rare) assembles it through the general front end before the jitter schedule runs
+  const bool small = c->fit_small && c->potrf_sched == 3 && c->inverse_inline && gp_small_applies(c);
+  if (small) {
+    ls_stage[d] = hyp->amp, ls_stage[d + 1] = hyp->noise, ls_stage[d + 2] = hyp->mean;
+    c->fitted = false;
+    c->model_kind = 0;
+    c->predicted = false;
+    c->amp = hyp->amp;
+    c->noise = hyp->noise;
+    c->mean = hyp->mean;
+  } else {
+    B7_HIP(c, hipMemcpyAsync(ls_dev, ls_stage, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
+    B7_TRY(fit_front(c, hyp, ls_dev));
+  }
 
   // First attempt with everything that follows it enqueued BEFORE the host looks at the pivot report: when the
   // inverse came out of the factorisation itself, alpha and the likelihood terms do not need the host, and one
@@ -598,11 +614,21 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
   const size_t blk_bytes = 16 + sizeof(double) * (nll_out ? 1 + ycols : 0);
   bool tail_done = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
+    if (small && attempt == 0) {
+      B7_TRY(launch_fit_small(c, 1, nullptr, ls_stage, ls_dev, (double *)c->w.p, (double *)c->zsc.p, (double *)c->zss.p, (double *)c->L.p,
+                              (double *)c->Linv.p, (double *)c->dinv.p, (double *)c->alpha.p, (double *)c->resid.p, (int *)c->info.p,
+                              nullptr));
+      c->linv_done = true;
+      c->alpha_done = false;
+      tail_done = true;
+      if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
+    } else {
     B7_TRY(launch_potrf(c, 0.0, true));
     tail_done = c->linv_done;
     if (tail_done) {
       B7_TRY(launch_alpha(c));
       if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
+    }
     }
     B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, tail_done ? blk_bytes : 16, hipMemcpyDeviceToHost, c->stream));
     if (then_predict && tail_done) {
@@ -625,6 +651,7 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
   bool predicted = then_predict && tail_done;
   if (info_first != 0) {
     c->fitted = false;
+    if (small) B7_TRY(fit_front(c, hyp, ls_dev));  // K(X,X) for the retries (the one-launch fit does not keep it)
     B7_TRY(jitter_retries(c, &jitter, true));
     tail_done = false;
     predicted = false;
@@ -701,7 +728,10 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     // 200 us is waited for the ordinary way, which also surfaces a fault.
     volatile unsigned *done = reinterpret_cast<volatile unsigned *>(const_cast<int *>(info) + 4 * (size_t)B);
     *done = 0u;
-    B7_TRY(launch_nll_small(c, B, pack_dev, pack, pack_dev + hyp_doubles, info_dev, reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B)));
+    if (c->nll_small == 2)
+      B7_TRY(launch_nll_small(c, B, pack_dev, pack, pack_dev + hyp_doubles, info_dev, reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B)));
+    else
+      B7_TRY(launch_nll_small8(c, B, pack_dev, pack, pack_dev + hyp_doubles, info_dev, reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B)));
     bool answered = false;
     if (B == 1) {
       const auto t0 = std::chrono::steady_clock::now();
@@ -963,7 +993,11 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   memset(reports, 0xff, rep_bytes);
   // the fits of all samples side by side in one persistent launch (one critical workgroup each) when that schedule serves
   // this size and the responses are a single column; otherwise one after the other
-  const bool batch = S > 1 && c->ycols == 1 && c->potrf_sched == 3 && c->Npad <= B7_PERSIST_NMAX && c->inverse_inline;
+  // N <= 128, d <= 32 (the reference's own regime): the whole fit of every hyper sample is one workgroup of ONE launch
+  // (gp_small.hip), for any S -- observation scaling, K(X,X), factorisation, inverse, alpha, the pivot reports into the mapped
+  // block; the kernel reads the hypers straight from that block and leaves the device copy the kernels downstream read
+  const bool small = c->fit_small && c->potrf_sched == 3 && c->inverse_inline && gp_small_applies(c);
+  const bool batch = small || (S > 1 && c->ycols == 1 && c->potrf_sched == 3 && c->Npad <= B7_PERSIST_NMAX && c->inverse_inline);
   const int n = c->Npad;
   const size_t nn = (size_t)n * n;
   if (batch) {
@@ -971,16 +1005,18 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
     B7_TRY(b7_ensure(c, c->bw, sizeof(double) * (size_t)S * c->dpad));
     B7_TRY(b7_ensure(c, c->bzsc, sizeof(double) * (size_t)S * n * c->dpad));
     B7_TRY(b7_ensure(c, c->bzss, sizeof(double) * (size_t)S * n));
-    B7_TRY(b7_ensure(c, c->bK, sizeof(double) * S * nn));
-    B7_TRY(b7_ensure(c, c->bL, sizeof(double) * S * nn));
     B7_TRY(b7_ensure(c, c->bLinv, sizeof(double) * S * nn));
-    B7_TRY(b7_ensure(c, c->bdinv, sizeof(double) * (size_t)S * n * B7_PANEL));
-    B7_TRY(b7_ensure(c, c->bflags, sizeof(unsigned) * S * fw));
     B7_TRY(b7_ensure(c, c->binfo, sizeof(int) * 4 * (size_t)S));
-    B7_TRY(b7_ensure(c, c->bresid, sizeof(double) * (size_t)S * n));
     B7_TRY(b7_ensure(c, c->balpha, sizeof(double) * (size_t)S * n));
+    if (!small) {
+      B7_TRY(b7_ensure(c, c->bK, sizeof(double) * S * nn));
+      B7_TRY(b7_ensure(c, c->bL, sizeof(double) * S * nn));
+      B7_TRY(b7_ensure(c, c->bdinv, sizeof(double) * (size_t)S * n * B7_PANEL));
+      B7_TRY(b7_ensure(c, c->bflags, sizeof(unsigned) * S * fw));
+      B7_TRY(b7_ensure(c, c->bresid, sizeof(double) * (size_t)S * n));
+    }
   }
-  B7_HIP(c, hipMemcpyAsync(c->bhyp.p, ls_host, ls_bytes, hipMemcpyHostToDevice, c->stream));
+  if (!small) B7_HIP(c, hipMemcpyAsync(c->bhyp.p, ls_host, ls_bytes, hipMemcpyHostToDevice, c->stream));
   double *fd = nullptr;
   if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
 
@@ -989,11 +1025,16 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   if (batch) {
     const double *hyp_dev = (const double *)c->bhyp.p, *amp_dev = hyp_dev + (size_t)S * d, *noise_dev = amp_dev + S,
                  *mean_dev = noise_dev + S;
+    int *reports_dev = static_cast<int *>(c->pin_eval_dev);
+    if (small) {
+      const double *hyp_map = reinterpret_cast<const double *>(static_cast<const char *>(c->pin_eval_dev) + rep_bytes);
+      B7_TRY(launch_fit_small(c, S, hyp_map, ls_host, (double *)c->bhyp.p, (double *)c->bw.p, (double *)c->bzsc.p, (double *)c->bzss.p,
+                              nullptr, (double *)c->bLinv.p, nullptr, (double *)c->balpha.p, nullptr, (int *)c->binfo.p, reports_dev));
+    } else {
     hipLaunchKernelGGL(resid_batch_kernel, dim3((n + 255) / 256, S), dim3(256), 0, c->stream, (const double *)c->ybuf.p,
                        (double *)c->bresid.p, c->N, n, mean_dev);
     B7_TRY(launch_kxx_batch(c, S, hyp_dev, amp_dev, noise_dev, (double *)c->bw.p, (double *)c->bzsc.p, (double *)c->bzss.p,
                             (double *)c->bK.p));
-    int *reports_dev = static_cast<int *>(c->pin_eval_dev);
     if (n == 64 && c->potrf_small) {
       // one 64-block per fit: factorisation, inverse, alpha and the pivot report (mirrored into the mapped block) of all S fits
       // in ONE launch of S workgroups
@@ -1009,6 +1050,7 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
     } else {
       B7_TRY(launch_alpha_batch(c, S, (const double *)c->bLinv.p, (const double *)c->bresid.p, (double *)c->balpha.p));
       B7_HIP(c, hipMemcpyAsync(reports, c->binfo.p, rep_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     }
     }
     const size_t row_bytes = sizeof(double) * (size_t)n;

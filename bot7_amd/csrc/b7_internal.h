@@ -141,7 +141,10 @@ struct b7_ctx {
   bool persist_attr_set = false, persist_stamps = false;
   int persist_helpers = 0;   // cap on the helper workgroups (B7_PERSIST_HELPERS; 0 = one per remaining CU)
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
-  bool nll_small = true;     // b7_gp_nll_batch at Npad <= 128, d <= 32: the one-workgroup-per-evaluation kernel (B7_NLL_SMALL)
+  int nll_small = 1;         // b7_gp_nll_batch at Npad <= 128, d <= 32: the one-workgroup-per-evaluation kernel (B7_NLL_SMALL: 0 general
+                             // path, 1 gp_small_kernel (eight waves), 2 round 3's four-wave nll_small_kernel)
+  bool fit_small = true;     // b7_eval_nominate / b7_gp_fit_hyp at Npad <= 128, d <= 32, one response column: the whole fit of a hyper
+                             // vector in one workgroup of one launch (gp_small.hip; B7_FIT_SMALL=0: the general schedule)
   int persist_fault = -1;    // tests only (B7_PERSIST_FAULT): panel whose flag workgroup 0 withholds, to exercise the time-out
   int potrf_sched_saved = 0; // the schedule to return to after such a redo
   DevBuf part;   // argmax partials (value, index)
@@ -282,6 +285,13 @@ int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, con
                           int *report_dev);
 int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
                      unsigned *done_dev);
+// gp_small.hip
+bool gp_small_applies(const b7_ctx *c);
+int launch_nll_small8(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
+                      unsigned *done_dev);
+int launch_fit_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *hyp_out, double *w, double *zsc,
+                     double *zss, double *L, double *Linv, double *dinv, double *alpha, double *resid, int *info_dev,
+                     int *report_dev);
 // report_dev (nullable): device address of mapped host memory that receives the first report_words ints of the pivot report
 int launch_alpha(b7_ctx *c, int *report_dev = nullptr, int report_words = 0);  // resid, Linv -> alpha
 int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha, const int *report_src = nullptr,

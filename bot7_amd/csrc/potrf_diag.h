@@ -131,17 +131,34 @@ struct NoHook {
 // 1 <= j <= i <= 3, of A: nothing in step 0's factor phase reads or writes them) and fetches the next panel's tiles at
 // kb >= 2 (kb = 4 stands for the routine's tail, where waves 1..3 wait for wave 0's last inverse pair).  Apart from that
 // it must not touch A, X or T.
+// nlive (VAR >= 1): rows / columns [nlive, 64) of the block are padding -- exact identity rows that no real row couples to
+// (the small-problem kernels: N = 25 observations in a 64-block).  A 16-wide step that lies wholly in the padding has
+// nothing to factor: the chain would reproduce L = I, inv = I (+0.0 elsewhere) bit for bit in 1.6 us of dependent
+// instructions, so wave 0 writes the sixteen ones of the inverse instead and leaves the block as it is.  Everything else
+// (barriers, in-block updates, inverse doubling) runs as always.
+// Every thread of a 256-thread group passes exactly DIAG_CORE_BARRIERS workgroup barriers in here (VAR >= 1): waves beyond
+// the four that call diag_core keep in step with diag_bystander.
+constexpr int DIAG_CORE_BARRIERS = 10;
+template <class F>
+__device__ __forceinline__ void diag_bystander(F &&between) {
+  for (int bi = 0; bi < DIAG_CORE_BARRIERS; ++bi) {
+    between(bi);
+    __syncthreads();
+  }
+}
 template <int VAR, bool STAMP, class Hook = NoHook>
 __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__restrict__ X, double *__restrict__ T, int p,
                                           int *__restrict__ info, unsigned long long *__restrict__ stamps,
-                                          const Hook &hook = Hook()) {
+                                          const Hook &hook = Hook(), int nlive = NB) {
 #define B7_DIAG_STAMP(i) \
   if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   for (int kb = 0; kb < 4; ++kb) {
     const int o = kb * 16;
-    if (VAR >= 1 && wave == 0) {
+    if (VAR >= 1 && wave == 0 && o >= nlive) {
+      if (lane < 16) X[(o + lane) * DLD + o + lane] = 1.0;  // a step wholly in the padding: inv = I, the block stays I (see nlive)
+    } else if (VAR >= 1 && wave == 0) {
       // Square-root-free pivot chain, built for ISSUE cycles: one wave issues a VALU instruction every ~5 cycles
       // and this routine is bound by that, not by latency (tools/valu_probe.hip).  Lane lr keeps row lr of
       // C = L diag(sqrt(d)) (c_ij = l_ij sqrt(d_j), pivots d_j = c_jj).  Per column j: broadcast d_j, r_j = 1/d_j
