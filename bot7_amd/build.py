@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libbot7hip.so")
-SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "potrf_persist.hip", "posterior.hip", "score.hip", "extras.hip", "comm.hip", "group.hip", "nll_small.hip", "blr_small.hip", "gp_small.hip"]
+SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "potrf_persist.hip", "posterior.hip", "score.hip", "extras.hip", "comm.hip", "group.hip", "nll_small.hip", "blr_small.hip", "gp_small.hip", "kpost_small.hip"]
 HEADERS = [os.path.join(CSRC, "b7_internal.h"), os.path.join(CSRC, "gemm_f64.h"), os.path.join(CSRC, "potrf_diag.h"), os.path.join(CSRC, "comm_rccl.h"), os.path.join(CSRC, "ksx_exp.h"), os.path.join(CSRC, "exp_table.h"),
            os.path.join(ROOT, "include", "bot7hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

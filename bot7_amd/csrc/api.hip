@@ -172,6 +172,7 @@ int b7_create(b7_ctx **out, int device_id) {
   if (const char *pv = getenv("B7_PERSIST_FAULT")) c->persist_fault = atoi(pv);
   if (const char *pv = getenv("B7_NLL_SMALL")) c->nll_small = atoi(pv);  // 0: likelihoods of small sets through the general path too; 2: round 3's kernel
   if (const char *pv = getenv("B7_FIT_SMALL")) c->fit_small = atoi(pv) != 0;  // 0: small fits through the general schedule too
+  if (const char *pv = getenv("B7_KPOST_SMALL")) c->kpost_small = atoi(pv) != 0;  // 0: small posteriors through ksx_kernel + post_kernel too
   if (const char *pv = getenv("B7_SYRK_SMALL")) c->syrk_small = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_DEFER")) c->potrf_defer = atoi(pv) ? 1 : 0;
   if (const char *pv = getenv("B7_POTRF_GROUP")) {
@@ -1055,7 +1056,22 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
     }
     const size_t row_bytes = sizeof(double) * (size_t)n;
     const int64_t Mpad = round_up(c->M, B7_MROWS);
-    if ((size_t)Mpad * S * row_bytes <= c->ks_bytes) {
+    if (c->kpost_small && kpost_small_applies(c)) {
+      // N <= 128, d <= 32: K(X*,X), mean and variance of all S samples in ONE kernel that never stores K* (kpost_small.hip)
+      B7_TRY(b7_ensure(c, c->bmu, sizeof(double) * (size_t)S * c->M));
+      B7_TRY(b7_ensure(c, c->bvar, sizeof(double) * (size_t)S * c->M));
+      B7_TRY(launch_kpost_small(c, S, (const double *)c->grid[c->grid_cur].p, c->M, (const double *)c->bw.p, (const double *)c->bzsc.p,
+                                (const double *)c->bzss.p, (const double *)c->bLinv.p, (const double *)c->balpha.p, hyp_dev, 0.0, 0.0, 0.0,
+                                (double *)c->bmu.p, (double *)c->bvar.p, c->M));
+      if (spec->kind == B7_SCORE_EI)
+        B7_TRY(launch_ei_batch(c, S, (const double *)c->bmu.p, (const double *)c->bvar.p, c->M, fd, spec->tradeoff, c->M,
+                               (double *)c->acc.p));
+      else
+        B7_TRY(launch_cb_batch(c, S, (const double *)c->bmu.p, (const double *)c->bvar.p, c->M, spec->tradeoff, spec->upper,
+                               spec->sign, c->M, (double *)c->acc.p));
+      c->fitted = false;     // neither the context's fit slot nor its mean / variance vectors hold any of these samples
+      c->predicted = false;
+    } else if ((size_t)Mpad * S * row_bytes <= c->ks_bytes) {
       // K* of all S samples fits the workspace at once (the reference's default sizes: 2e4 candidates, tens to hundreds
       // of observations, 10 samples): K*, posterior and score:add of all samples in ONE launch each (grid.z / grid.y =
       // sample), the score summed over the samples in order inside the kernel
@@ -1285,6 +1301,9 @@ extern "C" {
 
 static int predict_into(b7_ctx *c, const double *xq, int64_t M, double *mu, double *var) {
   if (M == 0) return B7_OK;
+  if (c->kpost_small && c->model_kind == 0 && kpost_small_applies(c))  // small fits: one kernel, K* never stored
+    return launch_kpost_small(c, 1, xq, M, (const double *)c->w.p, (const double *)c->zsc.p, (const double *)c->zss.p,
+                              (const double *)c->Linv.p, (const double *)c->alpha.p, nullptr, c->amp, c->noise, c->mean, mu, var, M);
   const size_t row_bytes = sizeof(double) * (size_t)c->Npad;
   int64_t chunk = (int64_t)(c->ks_bytes / row_bytes) / B7_MROWS * B7_MROWS;
   if (chunk < B7_MROWS) chunk = B7_MROWS;

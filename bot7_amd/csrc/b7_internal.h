@@ -143,6 +143,8 @@ struct b7_ctx {
   int persist_aborts = 0;    // launches that gave up waiting and were redone with the launch schedule
   int nll_small = 1;         // b7_gp_nll_batch at Npad <= 128, d <= 32: the one-workgroup-per-evaluation kernel (B7_NLL_SMALL: 0 general
                              // path, 1 gp_small_kernel (eight waves), 2 round 3's four-wave nll_small_kernel)
+  bool kpost_small = true;   // GP posterior at Npad <= 128, d <= 32, one response column: K(X*,X), mean and variance in one kernel, K*
+                             // never stored (kpost_small.hip; B7_KPOST_SMALL=0: ksx_kernel + post_kernel)
   bool fit_small = true;     // b7_eval_nominate / b7_gp_fit_hyp at Npad <= 128, d <= 32, one response column: the whole fit of a hyper
                              // vector in one workgroup of one launch (gp_small.hip; B7_FIT_SMALL=0: the general schedule)
   int persist_fault = -1;    // tests only (B7_PERSIST_FAULT): panel whose flag workgroup 0 withholds, to exercise the time-out
@@ -285,6 +287,11 @@ int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, con
                           int *report_dev);
 int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
                      unsigned *done_dev);
+// kpost_small.hip
+bool kpost_small_applies(const b7_ctx *c);
+int launch_kpost_small(b7_ctx *c, int S, const double *xq, int64_t M, const double *w, const double *zsc, const double *zss,
+                       const double *Linv, const double *alpha, const double *hyp_dev, double amp, double noise, double mean,
+                       double *mu, double *var, int64_t sout);
 // gp_small.hip
 bool gp_small_applies(const b7_ctx *c);
 int launch_nll_small8(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,

@@ -26,6 +26,19 @@
 #include "ksx_exp.h"
 #include "potrf_diag.h"
 
+#ifdef B7_GS_STAMP
+// Diagnostic build only (tools/gp_small_stamps.py; never defined for the shipped library): workgroup 0's waves 0 and 4 record
+// s_memtime at their phase boundaries into a buffer nothing else reads.
+__device__ unsigned long long b7_gs_stamps[2 * 32 + 32];
+extern "C" int b7dbg_gs_stamps(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(b7_gs_stamps), sizeof(unsigned long long) * (2 * 32 + 32));
+}
+#define GS_STAMP(i)                                                                                          \
+  if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) b7_gs_stamps[(threadIdx.x >> 8) * 32 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define GS_STAMP(i)
+#endif
+
 namespace {
 using namespace b7diag;  // NB = 64, DLD, TLD, diag_core, diag_bystander
 
@@ -56,6 +69,9 @@ struct GsArgs {
   double *w, *zsc, *zss, *L, *Linv, *dinv, *alpha, *resid;  // L, dinv, resid nullable
 };
 
+// every barrier of this kernel orders LDS traffic only: its global stores are results for LATER kernels and stay in flight
+__device__ __forceinline__ void lds_barrier() { diag_barrier<true>(); }
+
 // rows 0..15 x columns 48..63 of a block about to be factored: I_16 (potrf_diag.h: the right-hand side of the inversion)
 __device__ __forceinline__ void identity_corner(double *A) {
   const int t = threadIdx.x;
@@ -69,39 +85,97 @@ __device__ __forceinline__ void zero_block(double *X) {
   }
 }
 
-// One 16 x 16 sub-tile (it, jt) of the 64 x 64 block (I0, J0) of K(X,X) + noise I -> T; rows / columns >= N are the identity.
+// One 16 x 16 sub-tile (it, jt) of the 64 x 64 block (I0, J0) of K(X,X) + noise I, in the accumulator layout (v[r]: row
+// 16 it + (lane >> 4) + 4 r, column 16 jt + (lane & 15)); rows / columns >= N are the identity.
 // x (z .* w)' on MFMA exactly as ksx_kernel forms it: A fragments are the raw rows, B fragments the raw columns' rows times w
-// (the product rounded once, as prep_obs_kernel rounds z .* w), a chain of v_mfma_f64_16x16x4 over the eight k-steps = the
-// ascending fma chain over the 32 (zero padded) dimensions.  A sub-tile wholly in the padding is written, not computed.
-__device__ __forceinline__ void k_tile(const double *__restrict__ obs, const double (&wq)[8], const double *__restrict__ hn,
-                                       const double *__restrict__ tab, int I0, int J0, int N, double noise, double *__restrict__ T,
-                                       int it, int jt) {
+// (the product rounded once, as prep_obs_kernel rounds z .* w), a chain of v_mfma_f64_16x16x4 over the k-steps = the ascending
+// fma chain over the (zero padded) dimensions; ks = dpad / 4 steps hold anything.  A sub-tile wholly in the padding is not
+// computed.
+__device__ __forceinline__ void k_tile_vals(const double *__restrict__ obs, const double (&wq)[8], const double *__restrict__ hn,
+                                            const double *__restrict__ tab, int I0, int J0, int N, double noise, int it, int jt,
+                                            int ks, double (&v)[4]) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int gj = J0 + 16 * jt + lr;
   if (I0 + 16 * it >= N || J0 + 16 * jt >= N) {  // wave-uniform
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * it + lq + 4 * r;
-      T[i * DLD + 16 * jt + lr] = (I0 + i == gj) ? 1.0 : 0.0;
-    }
+    for (int r = 0; r < 4; ++r) v[r] = (I0 + 16 * it + lq + 4 * r == gj) ? 1.0 : 0.0;
     return;
   }
   d4_t c = {0.0, 0.0, 0.0, 0.0};
   const double *ap = obs + (I0 + 16 * it + lr) * OLD + lq, *bp = obs + gj * OLD + lq;
+  // all sixteen fragment reads at once (the columns beyond dpad hold zeros); the chain runs over the k-steps that hold anything,
+  // in three wave-uniform pieces (2, +2, +4) instead of a branch per step
+  double af[8], bf[8];
 #pragma unroll
-  for (int k4 = 0; k4 < 8; ++k4) c = mfma_f64(ap[4 * k4], bp[4 * k4] * wq[k4], c);
+  for (int k4 = 0; k4 < 8; ++k4) af[k4] = ap[4 * k4], bf[k4] = bp[4 * k4] * wq[k4];
+  c = mfma_f64(af[0], bf[0], c);
+  c = mfma_f64(af[1], bf[1], c);
+  if (ks > 2) {
+    c = mfma_f64(af[2], bf[2], c);
+    c = mfma_f64(af[3], bf[3], c);
+  }
+  if (ks > 4) {
+#pragma unroll
+    for (int k4 = 4; k4 < 8; ++k4) c = mfma_f64(af[k4], bf[k4], c);
+  }
   const double hj = hn[gj];
   double arg[4], kv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) arg[r] = (c[r] - hn[I0 + 16 * it + lq + 4 * r]) - hj;
   amp_exp_nonpos4(arg, tab, kv);
+  // all four exponentials exist HERE, side by side: without this the optimiser sinks each of them into its own lane-divergent
+  // "not padding" branch below and the four 14-deep chains run one after the other (a sub-tile took 2000 cycles, not 900)
+  asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]));
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int i = 16 * it + lq + 4 * r, gi = I0 + i;
-    double v = kv[r];
-    if (gi >= N || gj >= N) v = (gi == gj) ? 1.0 : 0.0;
-    else if (gi == gj) v = v + noise;
-    T[i * DLD + 16 * jt + lr] = v;
+    const int gi = I0 + 16 * it + lq + 4 * r;
+    const bool pad = gi >= N || gj >= N, dgn = gi == gj;
+    const double x = dgn ? kv[r] + noise : kv[r];
+    v[r] = pad ? (dgn ? 1.0 : 0.0) : x;
+  }
+}
+__device__ __forceinline__ void tile_put(double *__restrict__ T, int it, int jt, const double (&v)[4]) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T[(16 * it + lq + 4 * r) * DLD + 16 * jt + lr] = v[r];
+}
+// the two chains of a wave's share of L21 = K21 inv(L11)' (column blocks C0 and C1 of its row strip): ap -> this lane's A
+// fragments of K21 (k-step t at ap[4 t]), xp -> inv(L11)'s row lr, k = lq (column block jb's fragments at xp[16 jb DLD + 4 t]).
+// All operands first, then the MFMAs: the chain never waits for LDS.
+template <int C0, int C1>
+__device__ __forceinline__ void l21_chains(const double *__restrict__ ap, const double *__restrict__ xp, d4_t (&l)[2]) {
+  constexpr int N0 = 4 * (C0 + 1), N1 = 4 * (C1 + 1), NA = N0 > N1 ? N0 : N1;
+  double aq[NA], x0[N0], x1[N1];
+#pragma unroll
+  for (int t = 0; t < NA; ++t) aq[t] = ap[4 * t];
+#pragma unroll
+  for (int t = 0; t < N0; ++t) x0[t] = xp[C0 * 16 * DLD + 4 * t];
+#pragma unroll
+  for (int t = 0; t < N1; ++t) x1[t] = xp[C1 * 16 * DLD + 4 * t];
+  l[0] = d4_t{0.0, 0.0, 0.0, 0.0};
+  l[1] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < NA; ++t) {
+    if (t < N0) l[0] = mfma_f64(aq[t], x0[t], l[0]);
+    if (t < N1) l[1] = mfma_f64(aq[t], x1[t], l[1]);
+  }
+}
+// the two chains of a wave's share of L21 inv(L11) (column blocks C0, C1): ap -> A fragments of L21 (k-step t at ap[4 t]),
+// xb -> inv(L11)[k = lq][column lr] (k-step t, column block jb at xb[4 t DLD + 16 jb]); k-steps t >= 4 jb only
+template <int C0, int C1>
+__device__ __forceinline__ void p_chains(const double *__restrict__ ap, const double *__restrict__ xb, d4_t (&pv)[2]) {
+  constexpr int F0 = 4 * C0, F1 = 4 * C1, FA = F0 < F1 ? F0 : F1;
+  double aq[16], x0[16], x1[16];
+#pragma unroll
+  for (int t = FA; t < 16; ++t) aq[t] = ap[4 * t];
+#pragma unroll
+  for (int t = F0; t < 16; ++t) x0[t] = xb[4 * t * DLD + 16 * C0];
+#pragma unroll
+  for (int t = F1; t < 16; ++t) x1[t] = xb[4 * t * DLD + 16 * C1];
+#pragma unroll
+  for (int t = FA; t < 16; ++t) {
+    if (t >= F0) pv[0] = mfma_f64(aq[t], x0[t], pv[0]);
+    if (t >= F1) pv[1] = mfma_f64(aq[t], x1[t], pv[1]);
   }
 }
 // q-th sub-tile of a diagonal block's lower triangle: (0,0) (1,0) (1,1) (2,0) ...
@@ -144,6 +218,7 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   const double *hyp = a.use_inline ? hin.v : a.hyp_mem;
   const double *ls = hyp + (size_t)b * d;
   const double amp = hyp[(size_t)B * d + b], noise = hyp[(size_t)B * (d + 1) + b], mean = hyp[(size_t)B * (d + 2) + b];
+  GS_STAMP(0);
   if (tid < 4) inf[tid] = 0;
   if (tid < 32) w[tid] = tid < d ? 1.0 / ls[tid] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
   if (tid < 128) {
@@ -161,7 +236,8 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       v[t] = idx < total ? a.xobs[idx] : 0.0;
     }
     for (int e = tid; e < 128 * OLD; e += GS_THREADS) obs[e] = 0.0;
-    __syncthreads();
+    lds_barrier();
+    GS_STAMP(1);
     const float rd = 1.0f / (float)d;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -174,10 +250,10 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < 128) {
     double s = 0.0;
-    for (int k = 0; k < 32; ++k) {
+    for (int k = 0; k < a.dpad; ++k) {  // the columns beyond dpad add (0 * 0) * 0
       const double x = obs[tid * OLD + k];
       s += (x * x) * w[k];  // Z_ss = (Z.^2) * inv_ls, :79
     }
@@ -198,39 +274,70 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       a.hyp_out[at] = hyp[at];
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (MODE == 1 && tid < npad) a.zss[(size_t)b * npad + tid] = tid < N ? hn[tid] : 1e300;  // padding: covariance exactly 0
+  GS_STAMP(2);
+  const int ks = a.dpad >> 2;  // k-steps that hold anything: the columns beyond dpad are zero (same bits with or without them)
   double wq[8];
 #pragma unroll
   for (int k4 = 0; k4 < 8; ++k4) wq[k4] = w[4 * k4 + lq];
-  // K11 -> B1: the ten sub-tiles on and below the diagonal, over all eight waves
-  for (int q = wave; q < 10; q += 8) {
-    int it, jt;
-    lower_tile(q, it, jt);
-    k_tile(obs, wq, hn, tab, 0, 0, N, noise, B1, it, jt);
+  // K11 -> B1.  The factor routine's first step reads column block 0 only and its first update the tiles (i, 1): those and
+  // (2,2) are the first round, one sub-tile per wave; (3,2) and (3,3) are not touched before step 1 and are assembled by
+  // waves 4, 5 while wave 0 is in step 0.
+  {
+    constexpr int R1_I[8] = {0, 1, 2, 3, 1, 2, 3, 2}, R1_J[8] = {0, 0, 0, 0, 1, 1, 1, 2};
+    double kv[4];
+    k_tile_vals(obs, wq, hn, tab, 0, 0, N, noise, R1_I[wave], R1_J[wave], ks, kv);
+    tile_put(B1, R1_I[wave], R1_J[wave], kv);
   }
   zero_block(B3);
-  __syncthreads();
-  identity_corner(B1);
-  __syncthreads();
-  // ---- block (0,0): factor and invert on waves 0..3; waves 4..7 assemble K21 -> B2 meanwhile, a round of sub-tiles in front of
-  // every other barrier of the routine
+  GS_STAMP(3);
+#ifdef B7_GS_STAMP
+  {  // the same sub-tile once more: what does a K sub-tile cost when its code is already in the instruction cache?
+    constexpr int R1_I[8] = {0, 1, 2, 3, 1, 2, 3, 2}, R1_J[8] = {0, 0, 0, 0, 1, 1, 1, 2};
+    double kv2[4];
+    GS_STAMP(14);
+    k_tile_vals(obs, wq, hn, tab, 0, 0, N, noise, R1_I[wave], R1_J[wave], ks, kv2);
+    tile_put(B1, R1_I[wave], R1_J[wave], kv2);
+    GS_STAMP(15);
+    if (blockIdx.x == 0 && lane == 0) b7_gs_stamps[16 + wave] = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);  // HW_ID.SIMD_ID
+  }
+#endif
+  identity_corner(B1);  // rows 0..15 x columns 48..63: sub-tile (0,3), which no K sub-tile writes
+  lds_barrier();
+  GS_STAMP(4);
+  // ---- block (0,0): factor and invert on waves 0..3; waves 4..7 assemble what is left of K11 and all of K21 -> B2 meanwhile,
+  // one sub-tile per wave in front of each of the routine's four long phases (the 16-column factor steps) and of its tail
   if (!aux) {
-    diag_core<1, false>(B1, B3, T, 0, inf, nullptr, NoHook(), N < NB ? N : NB);  // B1 -> L11 (lower), B3 = inv(L11)
+#ifdef B7_GS_STAMP
+    __shared__ unsigned long long dst_[24];  // the factor routine's own phase stamps (slots 2..17), block 0
+    diag_core<1, true, NoHook, true>(B1, B3, T, 0, inf, dst_, NoHook(), N < NB ? N : NB);
+    if (blockIdx.x == 0 && tid < 24) b7_gs_stamps[32 + 8 + tid] = dst_[tid];
+#else
+    diag_core<1, false, NoHook, true>(B1, B3, T, 0, inf, nullptr, NoHook(), N < NB ? N : NB);  // B1 -> L11 (lower), B3 = inv(L11)
+#endif
   } else {
-    diag_bystander([&](int bi) {
-      if (two && !(bi & 1) && (bi >> 1) < 4) {
-        const int q = (wave - 4) + 4 * (bi >> 1);
-        k_tile(obs, wq, hn, tab, 64, 0, N, noise, B2, q >> 2, q & 3);
+    diag_bystander<true>([&](int bi) {
+      if (bi & 1) return;
+      const int g = wave - 4, slot = 4 * (bi >> 1) + g;  // slots 0, 1: K11's (3,2), (3,3); slots 2..17: K21's sixteen
+      double kv[4];
+      if (slot < 2) {
+        k_tile_vals(obs, wq, hn, tab, 0, 0, N, noise, 3, 2 + slot, ks, kv);
+        tile_put(B1, 3, 2 + slot, kv);
+      } else if (two && slot < 18) {
+        const int q = slot - 2;
+        k_tile_vals(obs, wq, hn, tab, 64, 0, N, noise, q >> 2, q & 3, ks, kv);
+        tile_put(B2, q >> 2, q & 3, kv);
       }
     });
   }
+  GS_STAMP(5);
   // (diag_core ends with a barrier: everybody sees L11, inv(L11) and K21)
   double *Lb = MODE == 1 && a.L ? a.L + (size_t)b * npad * npad : nullptr;
   double *Lib = MODE == 1 ? a.Linv + (size_t)b * npad * npad : nullptr;
   double *dib = MODE == 1 && a.dinv ? a.dinv + (size_t)b * npad * NB : nullptr;
-  if (!aux) {
-    const int row = tid >> 2, part = tid & 3;
+  if (aux == two) {  // two blocks: the helper waves (the others have the longer share of L21 below); one block: waves 0..3
+    const int t4 = tid & 255, row = t4 >> 2, part = t4 & 3;
     if (MODE == 0) {  // z1 = inv(L11) r1: four lanes per row, ascending columns within each quarter, then the quarters in order
       double acc = 0.0;
       for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(B3[row * DLD + k], r[k], acc);
@@ -239,102 +346,104 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       if (part == 0) z[row] = acc;
     }
     if (part == 0) dg[row] = B1[row * DLD + row];
-  } else if (Lb) {
-    store_block(B1, Lb, npad, true, tid - 256, 256);
-    if (two) store_zero_block(Lb + NB, npad, tid - 256, 256);
+  }
+  if (Lb) {
+    store_block(B1, Lb, npad, true, tid, GS_THREADS);
+    if (two) store_zero_block(Lb + NB, npad, tid, GS_THREADS);
   }
   if (two) {
-    // L21 = K21 inv(L11)': wave (rs, half) rows 16 rs .., column blocks 2 half, 2 half + 1; k ascending, blocks above inv(L11)'s
-    // diagonal skipped
-    const int rs = wave & 3, jb0 = 2 * (wave >> 2);
-    d4_t lv[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    {
-      const double *ap = B2 + (rs * 16 + lr) * DLD + lq, *xp = B3 + lr * DLD + lq;
+    // L21 = K21 inv(L11)': 16 x 16 sub-tile (rs, jb) is the chain over k-steps 0 .. 4 jb + 3 (blocks above inv(L11)'s diagonal
+    // skipped); wave (rs, 0) takes column blocks 0 and 3, wave (rs, 1) blocks 1 and 2: twenty MFMAs each
+    const int rs = wave & 3;
+    d4_t lv[2];
+    if (wave < 4)
+      l21_chains<0, 3>(B2 + (rs * 16 + lr) * DLD + lq, B3 + lr * DLD + lq, lv);
+    else
+      l21_chains<1, 2>(B2 + (rs * 16 + lr) * DLD + lq, B3 + lr * DLD + lq, lv);
+    const int jc0 = wave < 4 ? 0 : 1, jc1 = wave < 4 ? 3 : 2;
+    GS_STAMP(6);
+    lds_barrier();  // every wave is done reading K21, and L11 has been taken out of B1
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const double aq = ap[4 * t];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (jb0 + j >= (t >> 2)) lv[j] = mfma_f64(aq, xp[(jb0 + j) * 16 * DLD + 4 * t], lv[j]);
-      }
+    for (int rr = 0; rr < 4; ++rr) {
+      B2[(rs * 16 + lq + 4 * rr) * DLD + jc0 * 16 + lr] = lv[0][rr];
+      B2[(rs * 16 + lq + 4 * rr) * DLD + jc1 * 16 + lr] = lv[1][rr];
     }
-    __syncthreads();  // every wave is done reading K21 (and L11 has been taken out of B1)
+    lds_barrier();
+    GS_STAMP(7);
+    // K22 - L21 L21' -> B1, lower sub-tiles only, a sub-tile per wave (two for waves 0, 1): its K entries (registers), the
+    // 64-deep chain of L21 L21' from zero, then the subtraction
+    if (MODE == 0 && wave < 2) {  // r2 -= L21 z1: waves 0, 1 (their sub-tiles come last in the deal below), 32 rows a pass
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) B2[(rs * 16 + lq + 4 * rr) * DLD + (jb0 + j) * 16 + lr] = lv[j][rr];
-    __syncthreads();
-    d4_t u[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    d4_t pv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    if (!aux) {
-      // K22 - L21 L21' on the lower sub-tiles of row strip `wave`: the 64-deep chain from zero (subtracted below, once waves
-      // 4..7 have put K22 in place)
-      const double *ar = B2 + (16 * wave + lr) * DLD + lq;
-#pragma unroll
-      for (int k4 = 0; k4 < 16; ++k4) {
-        const double af = ar[4 * k4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-          if (jb <= wave) u[jb] = mfma_f64(af, B2[(16 * jb + lr) * DLD + lq + 4 * k4], u[jb]);
-      }
-      if (MODE == 0) {  // r2 -= L21 z1
-        const int row = tid >> 2, part = tid & 3;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = 32 * pass + (tid >> 2), part = tid & 3;
         double acc = 0.0;
         for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(B2[row * DLD + k], z[k], acc);
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         if (part == 0) r[64 + row] = r[64 + row] - acc;
-      } else {
-        // L21 inv(L11): the first (and only) 64-deep chunk of inv_job's partial sums, k ascending; inv(L11) is lower
-        // triangular, the k-steps above column block jb's diagonal hold zeros and are skipped (they add nothing)
-#pragma unroll
-        for (int k4 = 0; k4 < 16; ++k4) {
-          const double af = ar[4 * k4];
-#pragma unroll
-          for (int jb = 0; jb < 4; ++jb)
-            if (k4 >= 4 * jb) pv[jb] = mfma_f64(af, B3[(4 * k4 + lq) * DLD + 16 * jb + lr], pv[jb]);
-        }
-      }
-    } else {
-      // K22 -> B1 (lower sub-tiles), then what of the first block goes to global memory
-      for (int q = wave - 4; q < 10; q += 4) {
-        int it, jt;
-        lower_tile(q, it, jt);
-        k_tile(obs, wq, hn, tab, 64, 64, N, noise, B1, it, jt);
-      }
-      if (MODE == 1) {
-        if (Lb) store_block(B2, Lb + (size_t)NB * npad, npad, false, tid - 256, 256);
-        store_block(B3, Lib, npad, true, tid - 256, 256);
-        store_zero_block(Lib + NB, npad, tid - 256, 256);
-        if (dib) store_block(B3, dib, NB, true, tid - 256, 256);
       }
     }
-    __syncthreads();  // K22 is in B1; nobody reads the observations or L21's image any more
-    if (!aux) {
+    // sub-tile q goes to wave (q + 2) mod 8: the first six -- all there is to compute up to N = 112 -- land on waves 2..7
+    for (int q = (wave + 6) & 7; q < 10; q += 8) {
+      int it, jt;
+      lower_tile(q, it, jt);
+      if (NB + 16 * it >= N) {  // a row strip wholly in the padding: K is the identity there and L21's rows are zero (u = +0)
+        const double one[4] = {it == jt && lq == lr ? 1.0 : 0.0, it == jt && lq + 4 == lr ? 1.0 : 0.0, it == jt && lq + 8 == lr ? 1.0 : 0.0,
+                               it == jt && lq + 12 == lr ? 1.0 : 0.0};
+        tile_put(B1, it, jt, one);
+        continue;
+      }
+      double av[16], bv[16], kv[4];
+      const double *ar = B2 + (16 * it + lr) * DLD + lq, *br = B2 + (16 * jt + lr) * DLD + lq;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+      for (int k4 = 0; k4 < 16; ++k4) av[k4] = ar[4 * k4], bv[k4] = br[4 * k4];
+      k_tile_vals(obs, wq, hn, tab, 64, 64, N, noise, it, jt, ks, kv);
+      d4_t u = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-          if (jb <= wave) {
-            const int e = (16 * wave + lq + 4 * rr) * DLD + 16 * jb + lr;
-            B1[e] = B1[e] - u[jb][rr];
-          }
-      if (MODE == 1) {
+      for (int k4 = 0; k4 < 16; ++k4) u = mfma_f64(av[k4], bv[k4], u);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+      for (int rr = 0; rr < 4; ++rr) B1[(16 * it + lq + 4 * rr) * DLD + 16 * jt + lr] = kv[rr] - u[rr];
+    }
+    d4_t pv[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (MODE == 1) {
+      // L21 inv(L11): the first (and only) 64-deep chunk of inv_job's partial sums, k ascending; inv(L11) is lower triangular,
+      // the k-steps above column block jb's diagonal hold zeros and are skipped (they add nothing).  Column blocks as above.
+      if (wave < 4)
+        p_chains<0, 3>(B2 + (rs * 16 + lr) * DLD + lq, B3 + lq * DLD + lr, pv);
+      else
+        p_chains<1, 2>(B2 + (rs * 16 + lr) * DLD + lq, B3 + lq * DLD + lr, pv);
+      // what of block row 0 and of L21 goes to global memory (the images are read-only in this phase)
+      if (Lb) store_block(B2, Lb + (size_t)NB * npad, npad, false, tid, GS_THREADS);
+      store_block(B3, Lib, npad, true, tid, GS_THREADS);
+      store_zero_block(Lib + NB, npad, tid, GS_THREADS);
+      if (dib) store_block(B3, dib, NB, true, tid, GS_THREADS);
+    }
+    GS_STAMP(8);
+    lds_barrier();  // nobody reads the observations or L21's image any more
+    GS_STAMP(9);
+    if (MODE == 1) {
 #pragma unroll
-          for (int jb = 0; jb < 4; ++jb) B2[(16 * wave + lq + 4 * rr) * DLD + 16 * jb + lr] = 0.0 + pv[jb][rr];  // inv_job: tot = tot + cur
+      for (int rr = 0; rr < 4; ++rr) {  // inv_job: tot = tot + cur
+        B2[(rs * 16 + lq + 4 * rr) * DLD + jc0 * 16 + lr] = 0.0 + pv[0][rr];
+        B2[(rs * 16 + lq + 4 * rr) * DLD + jc1 * 16 + lr] = 0.0 + pv[1][rr];
       }
     }
     zero_block(B0);
-    __syncthreads();
-    identity_corner(B1);
-    __syncthreads();
+    identity_corner(B1);  // rows 0..15 x columns 48..63: sub-tile (0,3), which nobody above wrote
+    lds_barrier();
+    GS_STAMP(10);
     if (!aux) {
-      diag_core<1, false>(B1, B0, T, 1, inf, nullptr, NoHook(), N - NB);  // B1 -> L22, B0 = inv(L22)
+#ifdef B7_GS_STAMP
+      __shared__ unsigned long long dst2_[24];
+      diag_core<1, true, NoHook, true>(B1, B0, T, 1, inf, dst2_, NoHook(), N - NB);
+      if (blockIdx.x == 0 && tid < 24) b7_gs_stamps[64 + tid] = dst2_[tid];
+#else
+      diag_core<1, false, NoHook, true>(B1, B0, T, 1, inf, nullptr, NoHook(), N - NB);  // B1 -> L22, B0 = inv(L22)
+#endif
     } else {
-      diag_bystander([&](int) {});
+      diag_bystander<true>([&](int) {});
     }
+    GS_STAMP(11);
     if (!aux) {
       const int row = tid >> 2, part = tid & 3;
       if (MODE == 0) {
@@ -347,46 +456,50 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       if (part == 0) dg[64 + row] = B1[row * DLD + row];
     }
     if (MODE == 1) {
-      // inv(L)21 = -inv(L22) (L21 inv(L11)): inv_job's epilogue -- per column block two accumulators that take the k-steps of
-      // every 16-block alternately, blocks above inv(L22)'s diagonal skipped, their sum at the end
-      const int rs2 = wave & 3, s0 = 2 * (wave >> 2);
+      // inv(L)21 = -inv(L22) (L21 inv(L11)): inv_job's epilogue -- per sub-tile two accumulators that take the k-steps of
+      // every 16-block alternately, blocks above inv(L22)'s diagonal skipped, their sum at the end.  Wave (rs, half) takes
+      // sub-tiles (rs, 2 half) and (3 - rs, 2 half + 1): twenty MFMAs each
+      const int half = wave >> 2;
       d4_t outv[2];
 #pragma unroll
       for (int si = 0; si < 2; ++si) {
-        const int s = s0 + si;
+        const int rr2 = si == 0 ? rs : 3 - rs, s = 2 * half + si;
         d4_t c0a = {0.0, 0.0, 0.0, 0.0}, c1a = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
-          if (kq > rs2) break;
+          if (kq > rr2) break;
 #pragma unroll
           for (int s4 = 0; s4 < 4; s4 += 2) {
-            c0a = mfma_f64(-B0[(rs2 * 16 + lr) * DLD + kq * 16 + 4 * s4 + lq], B2[(kq * 16 + 4 * s4 + lq) * DLD + 16 * s + lr], c0a);
-            c1a = mfma_f64(-B0[(rs2 * 16 + lr) * DLD + kq * 16 + 4 * s4 + 4 + lq], B2[(kq * 16 + 4 * s4 + 4 + lq) * DLD + 16 * s + lr],
+            c0a = mfma_f64(-B0[(rr2 * 16 + lr) * DLD + kq * 16 + 4 * s4 + lq], B2[(kq * 16 + 4 * s4 + lq) * DLD + 16 * s + lr], c0a);
+            c1a = mfma_f64(-B0[(rr2 * 16 + lr) * DLD + kq * 16 + 4 * s4 + 4 + lq], B2[(kq * 16 + 4 * s4 + 4 + lq) * DLD + 16 * s + lr],
                            c1a);
           }
         }
         outv[si] = c0a + c1a;
       }
-      __syncthreads();
+      GS_STAMP(23);
+      lds_barrier();
 #pragma unroll
-      for (int si = 0; si < 2; ++si)
+      for (int si = 0; si < 2; ++si) {
+        const int rr2 = si == 0 ? rs : 3 - rs, s = 2 * half + si;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) B2[(rs2 * 16 + lq + 4 * rr) * DLD + 16 * (s0 + si) + lr] = outv[si][rr];
-      __syncthreads();
+        for (int rr = 0; rr < 4; ++rr) B2[(rr2 * 16 + lq + 4 * rr) * DLD + 16 * s + lr] = outv[si][rr];
+      }
+      lds_barrier();
+      GS_STAMP(24);
       store_block(B2, Lib + (size_t)NB * npad, npad, false, tid, GS_THREADS);
       store_block(B0, Lib + (size_t)NB * npad + NB, npad, true, tid, GS_THREADS);
       if (dib) store_block(B0, dib + NB * NB, NB, true, tid, GS_THREADS);
       if (Lb) store_block(B1, Lb + (size_t)NB * npad + NB, npad, true, tid, GS_THREADS);
     }
   } else if (MODE == 1) {
-    if (tid < 256) {
-      store_block(B3, Lib, npad, true, tid, 256);
-      if (dib) store_block(B3, dib, NB, true, tid, 256);
-    }
+    store_block(B3, Lib, npad, true, tid, GS_THREADS);
+    if (dib) store_block(B3, dib, NB, true, tid, GS_THREADS);
   }
 
+  GS_STAMP(12);
   if (MODE == 0) {
-    __syncthreads();
+    lds_barrier();
     // |z|^2 and sum log L_ii in a fixed order: a butterfly inside each wave, then the waves in order (nll_small_kernel's)
     double ssq = 0.0, ld = 0.0;
     if (tid < npad) {
@@ -402,7 +515,7 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       red[wave] = ssq;
       red[4 + wave] = ld;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       a.terms[2 * b] = (red[0] + red[1]) + (red[2] + red[3]);
       a.terms[2 * b + 1] = (red[4] + red[5]) + (red[6] + red[7]);
@@ -410,27 +523,44 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   } else {
     double *alb = a.alpha + (size_t)b * npad;
     if (two) {
-      // t = inv(L) r, row by row as trmv_lower_kernel sums it: lane k takes columns k and k + 64 (k <= row), then the butterfly
+      // t = inv(L) r, row by row as trmv_lower_kernel sums it: lane k takes columns k and k + 64 (k <= row), then the
+      // butterfly; a wave's sixteen rows side by side
+      double sv[16];
+#pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = 16 * wave + i;
         const double *l0 = row < NB ? B3 + row * DLD : B2 + (row - NB) * DLD;  // columns 0..63 of the row
         double s = 0.0;
         if (lane <= row) s = __builtin_fma(l0[lane], r[lane], s);
         if (row >= NB && lane + NB <= row) s = __builtin_fma(B0[(row - NB) * DLD + lane], r[NB + lane], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) tv[row] = s;
+        sv[i] = s;
       }
-      __syncthreads();
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] += __shfl_xor(sv[i], o);
+      GS_STAMP(20);
+      if (lane < 16) {
+        double mine = sv[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mine = lane == i ? sv[i] : mine;
+        tv[16 * wave + lane] = mine;
+      }
+      lds_barrier();
+      GS_STAMP(21);
       // alpha = inv(L)' t as trmv_lower_t_part_kernel / _sum_kernel sum it: per column the chain over rows 0..63 and the chain
       // over rows 64..127 (each ascending from zero), ((first + second) + 0) + 0, then 0 + that
       if (tid < 128) {
         const int col = tid;
         double s0 = 0.0, s1 = 0.0;
         if (col < NB) {
-          for (int i = 0; i < NB; ++i) s0 = __builtin_fma(B3[i * DLD + col], tv[i], s0);
-          for (int i = 0; i < NB; ++i) s1 = __builtin_fma(B2[i * DLD + col], tv[NB + i], s1);
+#pragma unroll 8
+          for (int i = 0; i < NB; ++i) {
+            s0 = __builtin_fma(B3[i * DLD + col], tv[i], s0);
+            s1 = __builtin_fma(B2[i * DLD + col], tv[NB + i], s1);
+          }
         } else {
+#pragma unroll 8
           for (int i = 0; i < NB; ++i) s1 = __builtin_fma(B0[i * DLD + (col - NB)], tv[NB + i], s1);
         }
         double part = ((s0 + s1) + 0.0) + 0.0;
@@ -448,15 +578,17 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
         acc += __shfl_xor(acc, 2);
         if (part == 0) tv[row] = acc;
       }
-      __syncthreads();
+      lds_barrier();
       if (tid < NB) {
         double acc = 0.0;
         for (int i = tid; i < NB; ++i) acc = __builtin_fma(B3[i * DLD + tid], tv[i], acc);
         alb[tid] = tid < N ? acc : 0.0;
       }
     }
+    GS_STAMP(22);
     if (a.resid && tid < npad) a.resid[(size_t)b * npad + tid] = r[tid];
   }
+  GS_STAMP(13);
   if (tid == 0) {
     if (a.info)
       for (int k = 0; k < 4; ++k) a.info[4 * b + k] = inf[k];
@@ -469,6 +601,7 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
     if (tid == 0) __hip_atomic_store(a.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
 
 int ensure_gs_table(b7_ctx *c) {
   static bool done[64] = {false};

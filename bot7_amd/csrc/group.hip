@@ -145,8 +145,11 @@ int b7_group_create(b7_group **out, int n, const int *device_ids) {
     g->ctx.push_back(c);
   }
   const std::set<int> distinct(device_ids, device_ids + n);
-  const char *mode = getenv("B7_GROUP_EXCHANGE");  // "host": merge on the host even across distinct devices
-  g->use_rccl = (int)distinct.size() == n && !(mode && strcmp(mode, "host") == 0);
+  // B7_GROUP_EXCHANGE: "host" merges on the host even across distinct devices; "rccl" issues the grouped all-reduce even when
+  // members share a device (real RCCL refuses that at ncclCommInitAll; the tests' in-process double accepts it, which is how
+  // the grouped branch runs with n > 1 on a one-GPU box)
+  const char *mode = getenv("B7_GROUP_EXCHANGE");
+  g->use_rccl = ((int)distinct.size() == n && !(mode && strcmp(mode, "host") == 0)) || (mode && strcmp(mode, "rccl") == 0);
   if (g->use_rccl) {
     Rccl &r = rccl();
     ncclResult_t e = ncclSuccess;
@@ -379,18 +382,25 @@ int b7_group_eval_nominate(b7_group *g, int S, const b7_hyp *hyps, const b7_scor
   // a fit that needed the jitter schedule (or a hand-off that timed out) redoes that member's nomination through the
   // per-sample path; the members fit the same matrices, so the first one's report speaks for all
   bool redone = false;
+  std::vector<char> member_redone(n, 0);
   for (int i = 0; i < n; ++i) {
     b7_ctx *c = g->ctx[i];
     if (c->M == 0 || eval_reports_clean(c, S)) continue;
+    if (hipSetDevice(c->device) != hipSuccess) return gfail(g, B7_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     G_TRY(g, i, eval_redo(c, S, hyps, spec, redone ? nullptr : jitter_out, redone ? nullptr : info_out));
     G_TRY(g, i, exch_local(c, (double)S, offset_of(g, i), i, n, g->use_rccl));
     redone = true;
+    member_redone[i] = 1;
   }
   if (redone) {
-    if (g->use_rccl)  // the table every member holds was summed with stale records: start again from the local ones
+    // After the first in-place all-reduce EVERY member's slots hold the whole summed table.  A redone member has just rewritten
+    // all of its slots (its new record, zeros elsewhere); every other member -- an empty shard included: its own slot is a
+    // valid zero record -- must go back to "own record, zeros elsewhere" too, or the second sum adds a stale copy of every
+    // record to the fresh ones
+    if (g->use_rccl)
       for (int i = 0; i < n; ++i) {
         b7_ctx *c = g->ctx[i];
-        if (c->M > 0 && eval_reports_clean(c, S)) {
+        if (!member_redone[i]) {
           if (hipSetDevice(c->device) != hipSuccess) return gfail(g, B7_ERR_HIP, "hipSetDevice(%d) failed", c->device);
           G_TRY(g, i, exch_rewrite_record(c, i, n));
         }

@@ -139,14 +139,27 @@ struct NoHook {
 // Every thread of a 256-thread group passes exactly DIAG_CORE_BARRIERS workgroup barriers in here (VAR >= 1): waves beyond
 // the four that call diag_core keep in step with diag_bystander.
 constexpr int DIAG_CORE_BARRIERS = 10;
-template <class F>
-__device__ __forceinline__ void diag_bystander(F &&between) {
-  for (int bi = 0; bi < DIAG_CORE_BARRIERS; ++bi) {
-    between(bi);
+// LB: the routine's barriers order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): a caller with global stores in flight
+// (gp_small.hip writes its results while the factorisation goes on) does not wait for them at every barrier, as
+// __syncthreads (vmcnt(0) as well) would.  Nothing inside the routine communicates through global memory.
+template <bool LB>
+__device__ __forceinline__ void diag_barrier() {
+  if constexpr (LB) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  } else {
     __syncthreads();
   }
 }
-template <int VAR, bool STAMP, class Hook = NoHook>
+template <bool LB = false, class F>
+__device__ __forceinline__ void diag_bystander(F &&between) {
+  for (int bi = 0; bi < DIAG_CORE_BARRIERS; ++bi) {
+    between(bi);
+    diag_barrier<LB>();
+  }
+}
+template <int VAR, bool STAMP, class Hook = NoHook, bool LB = false>
 __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__restrict__ X, double *__restrict__ T, int p,
                                           int *__restrict__ info, unsigned long long *__restrict__ stamps,
                                           const Hook &hook = Hook(), int nlive = NB) {
@@ -334,7 +347,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       }
     }
     B7_DIAG_STAMP(2 + 4 * kb);
-    __syncthreads();
+    diag_barrier<LB>();
     B7_DIAG_STAMP(3 + 4 * kb);
     // sub-panel: L_ik = A_ik * inv(L_kk)'  for block rows ib > kb, one 16x16 block per wave (VAR 1 solved it above)
     if (VAR == 0) {
@@ -347,7 +360,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) A[(ib * 16 + lq + 4 * rr) * DLD + o + lr] = c[rr];
       }
-      __syncthreads();
+      diag_barrier<LB>();
     }
     B7_DIAG_STAMP(4 + 4 * kb);
     // trailing update inside the block: A_ij -= L_ik L_jk'  for kb < j <= i < 4.  VAR 1 does only block column
@@ -364,7 +377,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
           block16_update(A, i, j, o, lr, lq);
         }
     }
-    __syncthreads();
+    diag_barrier<LB>();
     B7_DIAG_STAMP(5 + 4 * kb);
   }
 
@@ -383,7 +396,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) X[(c0 + lq + 4 * rr) * DLD + a0 + lr] = xx[rr];
   }
-  __syncthreads();
+  diag_barrier<LB>();
   {
     const int ti = wave >> 1, tj = wave & 1;
     if (VAR == 0) {
@@ -395,7 +408,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
-      __syncthreads();
+      diag_barrier<LB>();
     }
     d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -406,7 +419,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = x0[rr] + x1[rr];
   }
-  __syncthreads();
+  diag_barrier<LB>();
 #undef B7_DIAG_STAMP
 }
 

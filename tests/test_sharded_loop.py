@@ -392,15 +392,10 @@ def test_group_with_more_members_than_rows_and_shards_that_run_empty(ctx, orc):
 
 # ---- several PROCESSES, one GPU: the per-process communicator path with a test double for RCCL's transport ----------------
 def _stub_lib():
-    """tests/stub/rccl_shm_stub.cpp -> tests/stub/_build/librccl_shm_stub.so (hipcc; also built by __graft_entry__.build)."""
-    import subprocess
-    src = os.path.join(ROOT, "tests", "stub", "rccl_shm_stub.cpp")
-    out = os.path.join(ROOT, "tests", "stub", "_build", "librccl_shm_stub.so")
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-I/opt/rocm/include", "-o", out, src,
-                               "-Wl,-rpath,/opt/rocm/lib", "-lrt"])
-    return out
+    """tests/stub/rccl_shm_stub.cpp -> tests/stub/_build/librccl_shm_stub.so (tools/build_stub.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_stub import stub_lib
+    return stub_lib()
 
 
 @pytest.mark.gpu
@@ -450,6 +445,29 @@ def test_processes_sharing_the_gpu_run_the_trial_loop_through_the_communicator_p
 
 
 # ---- the boundary from plain C -----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_grouped_rccl_branch_runs_with_virtual_ranks(tmp_path):
+    """csrc/group.hip's grouped-RCCL branch (ncclCommInitAll, ncclGroupStart / one all-reduce per member / ncclGroupEnd, the
+    table read from member 0, the redo with rewritten records) with n = 2, 3, 8 members on ONE GPU: B7_GROUP_EXCHANGE=rccl
+    forces the branch for repeated device ids and the in-process test double (tests/stub) serves RCCL's entry points.  The
+    nomination must equal the single context's bit for bit -- the small-fit path (N = 100), the general one (N = 300), and a
+    5-candidate grid on 8 members (three shards empty) whose data need the jitter schedule: the redo must not sum a stale
+    table.  Real RCCL's transport across devices stays unmeasured (one GPU per box)."""
+    import json
+    import subprocess
+    out = str(tmp_path / "group.json")
+    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), B7_GROUP_EXCHANGE="rccl", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_group_worker.py"), out, "2", "3", "8"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.load(open(out))
+    assert len(res["cases"]) == 9
+    for c in res["cases"]:
+        assert c["uses_rccl"], c
+        assert c["easy"] and c["commit_row"] and c["commit_set"], c
+        assert c["jitter_needed"] and c["hard"], c
+
+
 def test_header_is_c99_and_cxx11():
     """include/bot7hip.h is the drop-in boundary: it must compile as C (what cgo / LuaJIT's cdef / ctypes users assume) and as
     C++, warning-free and pedantic."""
