@@ -100,6 +100,7 @@ PhaseScope::~PhaseScope() {
 static double *cur_grid(b7_ctx *c) { return (double *)c->grid[c->grid_cur].p; }
 
 static void invalidate_predictions(b7_ctx *c) {
+  c->pend.on = false;  // a batched score nobody collected belongs to the grid that just changed
   c->predicted = false;
   c->acc_valid = false;
   c->Mfeat = 0;  // DNGO features belong to the grid they were computed from
@@ -208,7 +209,7 @@ void b7_destroy(b7_ctx *c) {
                    &c->Linv,    &c->W,       &c->dinv, &c->alpha, &c->resid, &c->info,   &c->ybuf,   &c->mu,
                    &c->var,     &c->acc,     &c->ks,   &c->part,  &c->scratch, &c->tmpgrid, &c->tmpmu, &c->tmpvar, &c->fant, &c->feat, &c->netbuf, &c->atmp, &c->slots, &c->pstamps,
                    &c->bhyp, &c->bw, &c->bzsc, &c->bzss, &c->bK, &c->bL, &c->bdinv, &c->bflags, &c->binfo, &c->bresid, &c->bterms,
-                   &c->bLinv, &c->balpha, &c->bmu, &c->bvar};
+                   &c->bLinv, &c->balpha, &c->bmu, &c->bvar, &c->ticket};
   for (auto &kv : c->pjobs_cache) b7_release(kv.second.buf);
   for (DevBuf *b : all) b7_release(*b);
   if (c->tev_init)
@@ -1021,6 +1022,7 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   double *fd = nullptr;
   if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
 
+  c->pend.on = false;
   c->acc_fresh = true;  // torch.zeros(X_hid:size(1)), bots/bayesopt.lua:69: declared, not launched -- the first score:add starts from 0.0
   c->acc_valid = true;
   if (batch) {
@@ -1063,12 +1065,11 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
       B7_TRY(launch_kpost_small(c, S, (const double *)c->grid[c->grid_cur].p, c->M, (const double *)c->bw.p, (const double *)c->bzsc.p,
                                 (const double *)c->bzss.p, (const double *)c->bLinv.p, (const double *)c->balpha.p, hyp_dev, 0.0, 0.0, 0.0,
                                 (double *)c->bmu.p, (double *)c->bvar.p, c->M));
-      if (spec->kind == B7_SCORE_EI)
-        B7_TRY(launch_ei_batch(c, S, (const double *)c->bmu.p, (const double *)c->bvar.p, c->M, fd, spec->tradeoff, c->M,
-                               (double *)c->acc.p));
-      else
-        B7_TRY(launch_cb_batch(c, S, (const double *)c->bmu.p, (const double *)c->bvar.p, c->M, spec->tradeoff, spec->upper,
-                               spec->sign, c->M, (double *)c->acc.p));
+      // score:add of the S samples is left to the exchange step, which runs it fused with score:div, the arg-max and the record
+      c->pend.on = true;
+      c->pend.kind = spec->kind, c->pend.S = S, c->pend.upper = spec->upper;
+      c->pend.mu = (const double *)c->bmu.p, c->pend.var = (const double *)c->bvar.p, c->pend.fd = fd;
+      c->pend.stride = c->M, c->pend.tradeoff = spec->tradeoff, c->pend.sign = spec->sign;
       c->fitted = false;     // neither the context's fit slot nor its mean / variance vectors hold any of these samples
       c->predicted = false;
     } else if ((size_t)Mpad * S * row_bytes <= c->ks_bytes) {

@@ -101,6 +101,16 @@ struct b7_ctx {
   bool blr_small = true;     // b7_blr_eval_nominate: the head for z <= 64 features in one workgroup of one launch (blr_small.hip)
   double fmin_scalar = 0.0;  // f_min of a single response column: a kernel argument of the EI kernels (launched with fmin_dev == nullptr), no staging copy
   bool acc_fresh = false;  // the accumulator stands for zeros that were never written: the next score launch onto it starts from 0.0
+  // b7_eval_nominate's batched score (all S samples' mean / variance on the device), not launched yet: the exchange step runs it
+  // fused with score:div, the arg-max and the record (score.hip: score_finish_slot_kernel); anybody else who needs the
+  // accumulator first flushes it through the plain batch kernel (score_flush_pending)
+  struct PendingScore {
+    bool on = false;
+    int kind = 0, S = 0, upper = 0;
+    const double *mu = nullptr, *var = nullptr, *fd = nullptr;
+    int64_t stride = 0;
+    double tradeoff = 0.0, sign = 0.0;
+  } pend;
   DevBuf ks;     // K(X*,X) chunk workspace
   size_t ks_bytes = (size_t)4 << 30;
   int diag_variant = 1;  // 64x64 diagonal-block kernel: 0 = rsqrt pivot chain, 1 = square-root-free chain with the DPP-fused
@@ -150,6 +160,7 @@ struct b7_ctx {
   int persist_fault = -1;    // tests only (B7_PERSIST_FAULT): panel whose flag workgroup 0 withholds, to exercise the time-out
   int potrf_sched_saved = 0; // the schedule to return to after such a redo
   DevBuf part;   // argmax partials (value, index)
+  DevBuf ticket; // score_finish_slot_kernel's arrival counter (zero between launches)
   DevBuf scratch; // misc (fmin upload, results)
   DevBuf tmpgrid; // predict_at temporary grid
   DevBuf tmpmu, tmpvar;
@@ -346,6 +357,10 @@ int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64
                        int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec = nullptr,
                        unsigned *host_done = nullptr);
 
+int launch_score_finish_slot(b7_ctx *c, const b7_ctx::PendingScore &ps, double *acc, int64_t M, double divisor, uint64_t *tab_dev,
+                             int rank, int world, int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec = nullptr,
+                             unsigned *host_done = nullptr);
+int score_flush_pending(b7_ctx *c);
 int launch_keep_record(b7_ctx *c, uint64_t *tab_dev, int rank, int world);
 int launch_row_slot(b7_ctx *c, uint64_t *tab_dev, int rank, int world, int64_t idx1_global, int64_t local0, const double *grid,
                     int d);

@@ -79,7 +79,6 @@ void exch_forget(b7_ctx *c) { c->win_valid = false; }
 // (a context that nominates by itself: no copy launch and no stream wait between the arg-max and the answer; exch_wait_mirror)
 int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, bool all_slots, bool mirror) {
   B7_TRY(exch_table_ensure(c, world));
-  if (c->M > 0) B7_TRY(acc_materialize(c));
   uint64_t *host_rec = nullptr;
   unsigned *host_done = nullptr;
   if (mirror) {
@@ -87,6 +86,13 @@ int exch_local(b7_ctx *c, double divisor, int64_t offset, int rank, int world, b
     host_rec = c->tab_host_dev + (size_t)rank * B7_TAB_W;
     host_done = reinterpret_cast<unsigned *>(c->tab_host_dev + (size_t)(B7_MAX_WORLD + 1) * B7_TAB_W);
   }
+  if (c->M > 0 && c->pend.on) {  // the nomination's batched score is still owed: score:add x S, div, arg-max, record in ONE launch
+    const b7_ctx::PendingScore ps = c->pend;
+    c->pend.on = false;
+    return launch_score_finish_slot(c, ps, (double *)c->acc.p, c->M, divisor, (uint64_t *)c->slots.p, rank, world, offset,
+                                    (const double *)c->grid[c->grid_cur].p, c->d, all_slots, host_rec, host_done);
+  }
+  if (c->M > 0) B7_TRY(acc_materialize(c));
   return launch_finish_slot(c, c->M > 0 ? (double *)c->acc.p : nullptr, c->M, divisor, (uint64_t *)c->slots.p, rank, world,
                             offset, c->M > 0 ? (const double *)c->grid[c->grid_cur].p : nullptr, c->d, all_slots, host_rec,
                             host_done);

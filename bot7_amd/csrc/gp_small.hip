@@ -523,29 +523,30 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   } else {
     double *alb = a.alpha + (size_t)b * npad;
     if (two) {
-      // t = inv(L) r, row by row as trmv_lower_kernel sums it: lane k takes columns k and k + 64 (k <= row), then the
-      // butterfly; a wave's sixteen rows side by side
-      double sv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 16 * wave + i;
+      // t = inv(L) r with trmv_lower_kernel's sums: there a wave takes a row, lane k the columns k and k + 64 (k <= row), and a
+      // butterfly (xor 32, 16, ..., 1) adds the 64 partial sums.  Here a THREAD takes a row and walks the same binary tree over
+      // its 64 partial sums in registers -- level o adds element l and l + o for l < o, exactly the pairs lane 0 of the
+      // butterfly sees -- so the bits are the same and nothing crosses lanes (192 ds_bpermute per wave took 6 us).
+      if (tid < 128) {
+        const int row = tid;
         const double *l0 = row < NB ? B3 + row * DLD : B2 + (row - NB) * DLD;  // columns 0..63 of the row
-        double s = 0.0;
-        if (lane <= row) s = __builtin_fma(l0[lane], r[lane], s);
-        if (row >= NB && lane + NB <= row) s = __builtin_fma(B0[(row - NB) * DLD + lane], r[NB + lane], s);
-        sv[i] = s;
+        const double *l1 = B0 + (row < NB ? 0 : row - NB) * DLD;                // columns 64..127 (rows >= 64)
+        // no "k <= row" tests: the images hold +0.0 above the diagonals, and fma(0, r_k, s) = s (a lane-divergent branch per
+        // column cost 12 us here); rows 0..63 (wave 0) have no second column block at all
+        double p[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) p[k] = __builtin_fma(l0[k], r[k], 0.0);
+        if (wave == 1) {
+#pragma unroll
+          for (int k = 0; k < 64; ++k) p[k] = __builtin_fma(l1[k], r[NB + k], p[k]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int l = 0; l < o; ++l) p[l] = p[l] + p[l + o];
+        tv[row] = p[0];
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sv[i] += __shfl_xor(sv[i], o);
       GS_STAMP(20);
-      if (lane < 16) {
-        double mine = sv[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mine = lane == i ? sv[i] : mine;
-        tv[16 * wave + lane] = mine;
-      }
       lds_barrier();
       GS_STAMP(21);
       // alpha = inv(L)' t as trmv_lower_t_part_kernel / _sum_kernel sum it: per column the chain over rows 0..63 and the chain

@@ -51,13 +51,12 @@ __host__ __device__ constexpr int kp_lds_doubles(int nt) {
   return tri(nt) * 256 + nt * (DPAD / 4) * 64 + 32 * nt + DPAD + 128;
 }
 
-template <int DPAD>
+template <int DPAD, int NT>
 __global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
   constexpr int KS = DPAD / 4;
   extern __shared__ __align__(16) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
-  const int s = blockIdx.y, N = a.N, npad = a.npad, d = a.d;
-  const int NT = (N + 15) >> 4;
+  const int s = blockIdx.y, npad = a.npad, d = a.d;  // NT = ceil(N / 16) row strips hold observations (the launcher picks the instance)
   double *LF = sm, *ZF = LF + tri(NT) * 256, *zs = ZF + NT * KS * 64, *al = zs + 16 * NT, *wv = al + 16 * NT, *tab = wv + DPAD;
   const double amp = a.hyp ? a.hyp[(size_t)a.S * d + s] : a.amp;
   const double noise = a.hyp ? a.hyp[(size_t)a.S * (d + 1) + s] : a.noise;
@@ -107,42 +106,44 @@ __global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
       }
       hq = 0.5 * sx;
     }
-    d4_t acc[8];
+    d4_t acc[NT];
     double mac[4] = {0.0, 0.0, 0.0, 0.0};
     double ss[2] = {0.0, 0.0};
 #pragma unroll
-    for (int J = 0; J < 8; ++J) {
-      if (J < NT) {
-        // K*' tile J: rows = observations 16 J .., columns = candidates
-        d4_t c = {0.0, 0.0, 0.0, 0.0};
+    for (int J = 0; J < NT; ++J) {
+      // K*' tile J: rows = observations 16 J .., columns = candidates
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k4 = 0; k4 < KS; ++k4) c = mfma_f64(ZF[(J * KS + k4) * 64 + lane], xf[k4], c);
-        double hk[4], alj[4], arg[4], kv[4];
+      for (int k4 = 0; k4 < KS; ++k4) c = mfma_f64(ZF[(J * KS + k4) * 64 + lane], xf[k4], c);
+      double hk[4], alj[4], arg[4], kv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hk[r] = zs[16 * J + lq + 4 * r], alj[r] = al[16 * J + lq + 4 * r];
+      for (int r = 0; r < 4; ++r) hk[r] = zs[16 * J + lq + 4 * r], alj[r] = al[16 * J + lq + 4 * r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) arg[r] = (c[r] - hq) - hk[r];  // = -1/2 (((-2 c) + xs) + zs), utils/math.lua:82
-        amp_exp_nonpos4(arg, tab, kv);
+      for (int r = 0; r < 4; ++r) arg[r] = (c[r] - hq) - hk[r];  // = -1/2 (((-2 c) + xs) + zs), utils/math.lua:82
+      amp_exp_nonpos4(arg, tab, kv);
+      // all four exponentials exist HERE: left alone, the optimiser sinks each one in front of the k-step that consumes it
+      // and the four 14-deep chains run one after the other between the MFMAs
+      asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mac[r] = __builtin_fma(kv[r], alj[r], mac[r]);
-        // V[I] += L^-1[I][J] K*'[J] for the row strips I >= J; register q of the tile is the B operand of k-step q
+      for (int r = 0; r < 4; ++r) mac[r] = __builtin_fma(kv[r], alj[r], mac[r]);
+      // V[I] += L^-1[I][J] K*'[J] for the row strips I >= J; register q of the tile is the B operand of k-step q.  The
+      // fragments of a k-step first (NT - J independent reads), then its MFMAs (NT - J independent chains)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {
+        double af[NT];
 #pragma unroll
-          for (int I = J; I < 8; ++I) {
-            if (I < NT) {
-              const double af = LF[(tri(I) + J) * 256 + 64 * q + lane];
-              if (J == 0 && q == 0)
-                acc[I] = mfma_f64(af, kv[0], d4_t{0.0, 0.0, 0.0, 0.0});
-              else
-                acc[I] = mfma_f64(af, kv[q], acc[I]);
-            }
-          }
+        for (int I = J; I < NT; ++I) af[I] = LF[(tri(I) + J) * 256 + 64 * q + lane];
+#pragma unroll
+        for (int I = J; I < NT; ++I) {
+          if (J == 0 && q == 0)
+            acc[I] = mfma_f64(af[I], kv[0], d4_t{0.0, 0.0, 0.0, 0.0});
+          else
+            acc[I] = mfma_f64(af[I], kv[q], acc[I]);
         }
-        // row strip J is complete: its squares join the sum of its half (rows 16 J + g + 4 r, r ascending)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ss[J >> 2] = __builtin_fma(acc[J][r], acc[J][r], ss[J >> 2]);
       }
+      // row strip J is complete: its squares join the sum of its half (rows 16 J + g + 4 r, r ascending)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ss[J >> 2] = __builtin_fma(acc[J][r], acc[J][r], ss[J >> 2]);
     }
     // epilogue: the butterflies of ksx_kernel (mean) and post_kernel_w4 (variance)
     double v[4];
@@ -178,22 +179,49 @@ int ensure_kp_table(b7_ctx *c) {
   return B7_OK;
 }
 
-template <int DPAD>
+template <int DPAD, int NT>
 int kp_launch(b7_ctx *c, const KpArgs &a) {
   B7_TRY(ensure_kp_table(c));
-  const int nt = (a.N + 15) / 16;
-  const size_t lds = sizeof(double) * (size_t)kp_lds_doubles<DPAD>(nt);
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kpost_small_kernel<DPAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  const size_t lds = sizeof(double) * (size_t)kp_lds_doubles<DPAD>(NT);
+  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kpost_small_kernel<DPAD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-  // one workgroup per CU, the CUs split between the S fits; never more workgroups of a fit than it has strips for their waves
+  // workgroups per CU: two where the instance's registers (<= 128: four waves per SIMD) and LDS allow it, else one; the CUs'
+  // slots are split between the S fits; never more workgroups of a fit than it has strips for their waves
+  static int per_cu_cache = 0;  // per instantiation
+  if (per_cu_cache == 0) {
+    hipFuncAttributes fa;
+    B7_HIP(c, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kpost_small_kernel<DPAD, NT>)));
+    per_cu_cache = (fa.numRegs <= 128 && 2 * (lds + 512) <= (size_t)160 * 1024) ? 2 : 1;
+  }
   const int64_t nstrips = (a.M + 15) / 16;
-  int64_t gx = c->cus / a.S;
+  int64_t gx = (int64_t)per_cu_cache * c->cus / a.S;
   const int64_t need = (nstrips + (KP_THREADS / 64) - 1) / (KP_THREADS / 64);
   if (gx > need) gx = need;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(kpost_small_kernel<DPAD>, dim3((unsigned)gx, (unsigned)a.S), dim3(KP_THREADS), lds, c->stream, a);
+  hipLaunchKernelGGL((kpost_small_kernel<DPAD, NT>), dim3((unsigned)gx, (unsigned)a.S), dim3(KP_THREADS), lds, c->stream, a);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
+}
+
+// the instance for ceil(N / 16) row strips: all eight for the narrow classes (d <= 8: the regime the kernel is for), rounded up
+// to 4 / 8 for the wide ones (their padding strips multiply zeros: same bits, a bounded waste, a quarter of the binary)
+template <int DPAD>
+int kp_dispatch(b7_ctx *c, const KpArgs &a) {
+  const int nt = (a.N + 15) / 16;
+  if constexpr (DPAD <= 8) {
+    switch (nt) {
+      case 1: return kp_launch<DPAD, 1>(c, a);
+      case 2: return kp_launch<DPAD, 2>(c, a);
+      case 3: return kp_launch<DPAD, 3>(c, a);
+      case 4: return kp_launch<DPAD, 4>(c, a);
+      case 5: return kp_launch<DPAD, 5>(c, a);
+      case 6: return kp_launch<DPAD, 6>(c, a);
+      case 7: return kp_launch<DPAD, 7>(c, a);
+      default: return kp_launch<DPAD, 8>(c, a);
+    }
+  } else {
+    return nt <= 4 ? kp_launch<DPAD, 4>(c, a) : kp_launch<DPAD, 8>(c, a);
+  }
 }
 
 }  // namespace
@@ -214,10 +242,10 @@ int launch_kpost_small(b7_ctx *c, int S, const double *xq, int64_t M, const doub
   a.mu = mu, a.var = var, a.sout = sout;
   a.var_with_noise = c->opts.var_with_noise, a.clamp = c->opts.var_clamp, a.var_min = c->opts.var_min;
   switch (c->dpad) {
-    case 4: return kp_launch<4>(c, a);
-    case 8: return kp_launch<8>(c, a);
-    case 16: return kp_launch<16>(c, a);
-    case 32: return kp_launch<32>(c, a);
+    case 4: return kp_dispatch<4>(c, a);
+    case 8: return kp_dispatch<8>(c, a);
+    case 16: return kp_dispatch<16>(c, a);
+    case 32: return kp_dispatch<32>(c, a);
     default: return b7_fail(c, B7_ERR_UNSUPPORTED, "kpost_small: dpad %d", c->dpad);
   }
 }

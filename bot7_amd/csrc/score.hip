@@ -180,20 +180,10 @@ __global__ void __launch_bounds__(256) argmax_final_kernel(const Best *__restric
 // 1-based GLOBAL index, status 0, shard rows, the winner's grid row).  With all_slots the records of every other rank are
 // zeroed as well (comm.hip sums the tables of all ranks); a single-process group merges records on the host and needs
 // only this one.
-__global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict__ part, int n, unsigned long long *__restrict__ tab,
-                                                          int rank, int world, long long offset, long long rows,
-                                                          const double *__restrict__ grid, int d, int all_slots,
-                                                          long long forced_local, unsigned long long *__restrict__ host_rec,
-                                                          unsigned *__restrict__ host_done) {
-  __shared__ Best sh[4];
-  Best b{0.0, -1};
-  if (n > 0) {
-    for (int j = threadIdx.x; j < n; j += blockDim.x)
-      if (better(part[j], b)) b = part[j];
-    b = block_best(b, sh);
-  } else if (forced_local >= 0) {  // no scores: the record names a given row (b7_nominate_commit's broadcast)
-    b = Best{0.0, forced_local};
-  }
+// this rank's record (and, with all_slots, zeros for every other rank's) from the local best b; every thread of the block calls
+__device__ __forceinline__ void write_record(Best b, unsigned long long *__restrict__ tab, int rank, int world, long long offset,
+                                             long long rows, const double *__restrict__ grid, int d, int all_slots,
+                                             unsigned long long *__restrict__ host_rec, unsigned *__restrict__ host_done) {
   if (all_slots)
     for (int e = threadIdx.x; e < world * B7_TAB_W; e += blockDim.x)
       if (e / B7_TAB_W != rank) tab[e] = 0ull;
@@ -216,6 +206,91 @@ __global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+__global__ void __launch_bounds__(256) argmax_slot_kernel(const Best *__restrict__ part, int n, unsigned long long *__restrict__ tab,
+                                                          int rank, int world, long long offset, long long rows,
+                                                          const double *__restrict__ grid, int d, int all_slots,
+                                                          long long forced_local, unsigned long long *__restrict__ host_rec,
+                                                          unsigned *__restrict__ host_done) {
+  __shared__ Best sh[4];
+  Best b{0.0, -1};
+  if (n > 0) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+      if (better(part[j], b)) b = part[j];
+    b = block_best(b, sh);
+  } else if (forced_local >= 0) {  // no scores: the record names a given row (b7_nominate_commit's broadcast)
+    b = Best{0.0, forced_local};
+  }
+  write_record(b, tab, rank, world, offset, rows, grid, d, all_slots, host_rec, host_done);
+}
+
+// score:add over the S hyper samples of a nomination, score:div, score:max(1) and this rank's exchange record in ONE launch
+// (bots/bayesopt.lua:76-79, :96): ei_batch_kernel / cb_batch_kernel + finish_kernel + argmax_slot_kernel, the same operations in
+// the same order per candidate -- acc = ((0 + s_0) + s_1) + ..., acc / divisor -- then the per-block best, and the LAST block to
+// arrive (a ticket from one atomic counter; every block's partial is fenced before its ticket) reduces the partials and writes
+// the record.  Three dependent launches at the ~4.5 us dispatch floor each become one.
+struct ScoreArgs {
+  const double *mu, *var;
+  int S, kind;  // kind: B7_SCORE_EI / B7_SCORE_CB
+  long long sstride;
+  const double *fmin;
+  double fmin0, tradeoff, sign;
+  int upper, fresh;
+};
+__global__ void __launch_bounds__(256)
+    score_finish_slot_kernel(ScoreArgs sa, double *__restrict__ acc, long long M, double divisor, Best *__restrict__ part,
+                             unsigned *__restrict__ ticket, unsigned long long *__restrict__ tab, int rank, int world, long long offset,
+                             const double *__restrict__ grid, int d, int all_slots, unsigned long long *__restrict__ host_rec,
+                             unsigned *__restrict__ host_done) {
+  __shared__ Best sh[4];
+  __shared__ unsigned last;
+  Best b{0.0, -1};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
+    double a = sa.fresh ? 0.0 : acc[j];  // fresh: the accumulator is torch.zeros (bots/bayesopt.lua:69), not read
+    for (int s = 0; s < sa.S; ++s) {
+      const double m = sa.mu[s * sa.sstride + j], vr = sa.var[s * sa.sstride + j];
+      double sc;
+      if (sa.kind == B7_SCORE_EI) {
+        double sigma = sqrt(vr);
+        double imprv = ((sa.fmin ? sa.fmin[0] : sa.fmin0) + (-m)) + (-sa.tradeoff);
+        double z = imprv / sigma;
+        sc = (imprv * b7_norm_cdf(z)) + (sigma * b7_norm_pdf(z));
+        sc = (sc < 0.0) ? 0.0 : sc;
+      } else {
+        double sd = sqrt(vr) * sa.tradeoff;
+        sc = sa.upper ? (m + sd) : (m + (-sd));
+        sc = (sa.sign > 0.0) ? sc : -sc;
+      }
+      a = a + sc;
+    }
+    const double v = a / divisor;
+    acc[j] = v;
+    Best cnd{v, j};
+    if (better(cnd, b)) b = cnd;
+  }
+  b = block_best(b, sh);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = b;
+    __threadfence();  // the partial is visible device-wide before the ticket is taken
+    const unsigned t = atomicAdd(ticket, 1u);
+    last = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();  // the other blocks' partials, published before their tickets
+  Best f{0.0, -1};
+  for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x) {
+    Best pj;  // agent-scope loads: the partials of other CUs, not a stale line of this CU's cache
+    pj.v = __hip_atomic_load(&part[j].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pj.i = __hip_atomic_load(&part[j].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (better(pj, f)) f = pj;
+  }
+  __syncthreads();
+  f = block_best(f, sh);
+  if (threadIdx.x == 0) *ticket = 0u;  // ready for the next launch (stream order: nobody else touches it meanwhile)
+  write_record(f, tab, rank, world, offset, M, grid, d, all_slots, host_rec, host_done);
 }
 
 __global__ void __launch_bounds__(256) keep_record_kernel(unsigned long long *__restrict__ tab, int rank, int world) {
@@ -288,7 +363,17 @@ int launch_fill(b7_ctx *c, double *p, int64_t n, double v) {
 }
 
 // zeros that were only declared (acc_fresh) and never met a score launch: write them before anybody reads the accumulator
+// a batched score that b7_eval_nominate left for the fused finish (launch_score_finish_slot) and somebody else wants first
+int score_flush_pending(b7_ctx *c) {
+  if (!c->pend.on) return B7_OK;
+  const b7_ctx::PendingScore ps = c->pend;
+  c->pend.on = false;
+  if (ps.kind == B7_SCORE_EI) return launch_ei_batch(c, ps.S, ps.mu, ps.var, ps.stride, ps.fd, ps.tradeoff, c->M, (double *)c->acc.p);
+  return launch_cb_batch(c, ps.S, ps.mu, ps.var, ps.stride, ps.tradeoff, ps.upper, ps.sign, c->M, (double *)c->acc.p);
+}
+
 int acc_materialize(b7_ctx *c) {
+  B7_TRY(score_flush_pending(c));
   if (!c->acc_fresh) return B7_OK;
   c->acc_fresh = false;
   return launch_fill(c, (double *)c->acc.p, c->M, 0.0);
@@ -326,6 +411,28 @@ int launch_finish_slot(b7_ctx *c, double *acc, int64_t M, double divisor, uint64
   hipLaunchKernelGGL(argmax_slot_kernel, dim3(1), dim3(256), 0, c->stream, (const Best *)part, nb,
                      (unsigned long long *)tab_dev, rank, world, (long long)offset, (long long)M, grid, d, all_slots ? 1 : 0,
                      -1ll, (unsigned long long *)host_rec, host_done);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+// The fused form: the S-sample score, score:div, the local arg-max and the record in one launch.
+int launch_score_finish_slot(b7_ctx *c, const b7_ctx::PendingScore &ps, double *acc, int64_t M, double divisor, uint64_t *tab_dev,
+                             int rank, int world, int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec,
+                             unsigned *host_done) {
+  PhaseScope scope(c, "score");
+  const int nb = nblocks(c, M);
+  B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
+  Best *part = (Best *)c->part.p;
+  if (!c->ticket.p) {  // the ticket counter: a word of its own (c->part is shared scratch), zero between launches
+    B7_TRY(b7_ensure(c, c->ticket, 64));
+    B7_HIP(c, hipMemsetAsync(c->ticket.p, 0, 64, c->stream));
+  }
+  unsigned *ticket = (unsigned *)c->ticket.p;
+  ScoreArgs sa{ps.mu, ps.var, ps.S, ps.kind, (long long)ps.stride, ps.fd, c->fmin_scalar, ps.tradeoff, ps.sign, ps.upper,
+               acc_mode(c, acc, true) == 2 ? 1 : 0};
+  hipLaunchKernelGGL(score_finish_slot_kernel, dim3(nb), dim3(256), 0, c->stream, sa, acc, (long long)M, divisor, part, ticket,
+                     (unsigned long long *)tab_dev, rank, world, (long long)offset, grid, d, all_slots ? 1 : 0,
+                     (unsigned long long *)host_rec, host_done);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

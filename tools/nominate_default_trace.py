@@ -30,5 +30,19 @@ for d, N, fn in CASES:
             best = ctx.eval_nominate(hyps[:S], **spec)
             ts.append(time.perf_counter() - t0)
         ts = np.array(ts) * 1e6
-        print("d %d N %3d, 20000 candidates, %2d hyper samples: mean %.1f us per nomination, median %.1f, max %.0f at call %d (winner %s)"
-              % (d, N, S, ts.mean(), np.median(ts), ts.max(), int(ts.argmax()), best[1]), flush=True)
+        # the C call alone (what a Lua / C host pays): arguments packed once
+        from bot7_amd import _lib
+        import ctypes as C
+        L = _lib.load()
+        arr, keep = ctx._pack_hyps(hyps[:S], d)
+        sp, fm = ctx._pack_spec("ei", spec["fmin"], 0.0, False, -1.0)
+        v, i = C.c_double(), C.c_int64()
+        args = (ctx._h, S, arr, C.byref(sp), 0, C.byref(v), C.byref(i), None, None)
+        for _ in range(5):
+            L.b7_eval_nominate(*args)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            L.b7_eval_nominate(*args)
+        ccall = (time.perf_counter() - t0) / 200 * 1e6
+        print("d %d N %3d, 20000 candidates, %2d hyper samples: mean %.1f us per nomination, median %.1f, max %.0f at call %d (winner %s); C call alone %.1f us"
+              % (d, N, S, ts.mean(), np.median(ts), ts.max(), int(ts.argmax()), best[1], ccall), flush=True)
