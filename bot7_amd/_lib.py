@@ -66,27 +66,31 @@ class GpOpts(C.Structure):
                 ("var_clamp", C.c_int), ("var_min", C.c_double)]
 
 
-_lib = None
+_libs = {}
+# the DIAGNOSTIC build (python -m bot7_amd.build --diag: the A/B switches, the fault injector and the RCCL override compiled in);
+# test infrastructure, loaded BESIDE the shipped library by Context(..., lib="diag")
+_DIAG_SO = os.path.join(os.path.dirname(_HERE), "tools", "_build", "libbot7hip_diag.so")
 
 
-def lib_path():
-    return _SO
+def lib_path(which=None):
+    return _DIAG_SO if which == "diag" else _SO
 
 
-def load():
-    """Load libbot7hip.so once.  torch (when installed) is imported first so that both share ONE HIP runtime:
-    torch bundles its own libamdhip64 with the same SONAME, and whichever is mapped first serves both."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_SO):
-        raise Bot7HipError(-2, "%s not found: build it with `python -m bot7_amd.build` "
-                               "(there is no CPU fallback)" % _SO)
+def load(which=None):
+    """Load libbot7hip.so (or, which="diag", the diagnostic build beside it) once.  torch (when installed) is imported first so
+    that both share ONE HIP runtime: torch bundles its own libamdhip64 with the same SONAME, and whichever is mapped first
+    serves both."""
+    path = lib_path(which)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise Bot7HipError(-2, "%s not found: build it with `python -m bot7_amd.build%s` "
+                               "(there is no CPU fallback)" % (path, " --diag" if which == "diag" else ""))
     try:
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL if which != "diag" else C.RTLD_LOCAL)
     dp, vp, i64, i32, dbl = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_int, C.c_double
     sig = {
         "b7_abi_version": (i32, []),
@@ -175,7 +179,7 @@ def load():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -193,8 +197,9 @@ def _ptr(a):
 class Context(object):
     """One GPU's worth of state: the resident candidate grid, the current GP fit, the score accumulator."""
 
-    def __init__(self, device_id=0, _borrowed=None):
-        self._L = load()
+    def __init__(self, device_id=0, _borrowed=None, lib=None):
+        self._L = load(lib)
+        self._lib_name = lib
         if _borrowed is not None:   # a member of a Group: the handle belongs to the group
             self._h, self._owned = C.c_void_p(_borrowed), False
         else:
@@ -715,15 +720,15 @@ class Group(object):
     """One host process, several GPUs (b7_group_*): a candidate grid sharded over the members, the observations on every
     member, bayesopt:eval + nominate over the union as one call.  device_ids may repeat (virtual ranks on one device)."""
 
-    def __init__(self, device_ids):
-        self._L = load()
+    def __init__(self, device_ids, lib=None):
+        self._L = load(lib)
         ids = np.ascontiguousarray(np.asarray(device_ids, dtype=np.int32).ravel())
         h = C.c_void_p()
         rc = self._L.b7_group_create(C.byref(h), ids.size, _ptr(ids))
         if rc != B7_OK:
             raise Bot7HipError(rc, (self._L.b7_last_error(None) or b"").decode())
         self._h, self.n = h, int(ids.size)
-        self.members = [Context(int(ids[r]), _borrowed=self._L.b7_group_ctx(h, r)) for r in range(self.n)]
+        self.members = [Context(int(ids[r]), _borrowed=self._L.b7_group_ctx(h, r), lib=lib) for r in range(self.n)]
         self._data_d = -1
         self.grid_version = 0
 

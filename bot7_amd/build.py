@@ -16,7 +16,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libbot7hip.so")
-SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "potrf_persist.hip", "posterior.hip", "score.hip", "extras.hip", "comm.hip", "group.hip", "nll_small.hip", "blr_small.hip", "gp_small.hip", "kpost_small.hip"]
+SOURCES = ["api.hip", "sobol.hip", "covar.hip", "potrf.hip", "potrf_persist.hip", "posterior.hip", "score.hip", "extras.hip", "comm.hip", "group.hip", "blr_small.hip", "gp_small.hip", "kpost_small.hip"]
+# The DIAGNOSTIC build (tools/_build/libbot7hip_diag.so, -DB7_DIAG): the shipped sources + round 3's likelihood kernel kept as
+# a bit-for-bit reference.  Only translation units that mention B7_DIAG are compiled a second time; the rest are shared.
+DIAG_ONLY_SOURCES = ["nll_small.hip"]
+DIAG_OUT = os.path.join(ROOT, "tools", "_build", "libbot7hip_diag.so")
 HEADERS = [os.path.join(CSRC, "b7_internal.h"), os.path.join(CSRC, "gemm_f64.h"), os.path.join(CSRC, "potrf_diag.h"), os.path.join(CSRC, "comm_rccl.h"), os.path.join(CSRC, "ksx_exp.h"), os.path.join(CSRC, "exp_table.h"),
            os.path.join(ROOT, "include", "bot7hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -36,13 +40,34 @@ def _stale(target, deps):
 EXTRA_FLAGS = {"covar.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def _compile(src):
-    obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+def _compile(src, diag=False):
+    obj = os.path.join(BUILD, ("diag_" if diag else "") + src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS + [os.path.abspath(__file__)]):
-        subprocess.check_call([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj])
+        subprocess.check_call([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-DB7_DIAG"] if diag else []) + ["-c", path, "-o", obj])
         return obj, True
     return obj, False
+
+
+def _mentions_diag(src):
+    return "B7_DIAG" in open(os.path.join(CSRC, src)).read()
+
+
+def build_diag(verbose=False):
+    """tools/_build/libbot7hip_diag.so: the library with its A/B switches, fault injector and RCCL override compiled in (-DB7_DIAG).
+    Test infrastructure: tests load it BESIDE the shipped library (bot7_amd.Context(..., lib="diag"))."""
+    build()
+    os.makedirs(os.path.dirname(DIAG_OUT), exist_ok=True)
+    todo = [s for s in SOURCES if _mentions_diag(s)] + DIAG_ONLY_SOURCES
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+        res = dict(zip(todo, ex.map(lambda s: _compile(s, True), todo)))
+    objs = [res[s][0] if s in res else os.path.join(BUILD, s.replace(".hip", ".o")) for s in SOURCES + DIAG_ONLY_SOURCES]
+    if any(ch for _, ch in res.values()) or _stale(DIAG_OUT, objs):
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", DIAG_OUT] + objs +
+                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+        if verbose:
+            print("built", DIAG_OUT)
+    return DIAG_OUT
 
 
 def posterior_isa():
@@ -127,3 +152,5 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--diag" in sys.argv:
+        build_diag(verbose=True)

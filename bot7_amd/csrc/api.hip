@@ -159,9 +159,13 @@ int b7_create(b7_ctx **out, int device_id) {
   c->device = device_id;
   c->cus = prop.multiProcessorCount;
   b7_gp_default_opts(&c->opts);
-  // schedule switches (A/B baselines that tests/test_gpu_parity.py keeps honest): read once here, never in the launch paths
-  if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
+  // the one tunable of the shipped library, read once here, never in the launch paths
   if (const char *pv = getenv("B7_SPIN_US")) c->spin_us = atoi(pv);  // 0: never spin on a completion word, always wait for the stream
+#ifdef B7_DIAG
+  // DIAGNOSTIC build only (tools/_build/libbot7hip_diag.so, python -m bot7_amd.build --diag; tests load it beside the shipped
+  // library): the A/B arms that tests/test_gpu_parity.py holds against the default paths, stamp collection, the persistent
+  // schedule's fault injector.  None of these names exists in libbot7hip.so.
+  if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
   if (const char *pv = getenv("B7_NPAD_SMALL")) c->npad_small = atoi(pv) != 0;  // 0: pad N <= 64 (and <= 64 basis features) to 128 as N > 64
   if (const char *pv = getenv("B7_POTRF_SMALL")) c->potrf_small = atoi(pv) != 0;
   if (getenv("B7_POTRF_SCHED") || getenv("B7_DIAG_VARIANT") || getenv("B7_INVERSE_INLINE")) c->potrf_small = false;  // an explicit schedule is an A/B arm
@@ -180,6 +184,7 @@ int b7_create(b7_ctx **out, int device_id) {
     const int g = atoi(pv);
     if (g >= 1 && g <= 8) c->potrf_group = g;
   }
+#endif
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fit, hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc(&c->pinned, 16384, hipHostMallocMapped);
@@ -715,8 +720,8 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
   memcpy(pack + (size_t)B * d, amp, sizeof(double) * B);
   memcpy(pack + (size_t)B * (d + 1), noise, sizeof(double) * B);
   memcpy(pack + (size_t)B * (d + 2), mean, sizeof(double) * B);
-  if (c->nll_small && nll_small_applies(c)) {
-    // N <= 128, d <= 32: every evaluation is ONE workgroup of ONE launch (nll_small.hip), observations in, two numbers out.
+  if (c->nll_small && gp_small_applies(c)) {
+    // N <= 128, d <= 32: every evaluation is ONE workgroup of ONE launch (gp_small.hip), observations in, two numbers out.
     // A fit whose plain factorisation fails (rare) sends the whole batch through the general path below, jitter schedule
     // included.  The kernel reads the B x (d + 3) numbers and writes its 2 doubles + 4 ints per evaluation straight across
     // the bus -- no copy calls, one launch, one wait
@@ -730,9 +735,11 @@ int b7_gp_nll_batch(b7_ctx *c, int B, const double *lenscale_sq, const double *a
     // 200 us is waited for the ordinary way, which also surfaces a fault.
     volatile unsigned *done = reinterpret_cast<volatile unsigned *>(const_cast<int *>(info) + 4 * (size_t)B);
     *done = 0u;
-    if (c->nll_small == 2)
+#ifdef B7_DIAG
+    if (c->nll_small == 2)  // round 3's four-wave kernel (nll_small.hip, diagnostic build only): the bit-for-bit reference of the likelihood
       B7_TRY(launch_nll_small(c, B, pack_dev, pack, pack_dev + hyp_doubles, info_dev, reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B)));
     else
+#endif
       B7_TRY(launch_nll_small8(c, B, pack_dev, pack, pack_dev + hyp_doubles, info_dev, reinterpret_cast<unsigned *>(info_dev + 4 * (size_t)B)));
     bool answered = false;
     if (B == 1) {

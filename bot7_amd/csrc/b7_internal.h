@@ -205,12 +205,13 @@ struct b7_ctx {
 
 // ---- error helpers ---------------------------------------------------------------------------------
 int b7_fail(b7_ctx *c, int code, const char *fmt, ...);
-#define B7_HIP(c, expr)                                                                     \
-  do {                                                                                      \
-    hipError_t e__ = (expr);                                                                \
-    if (e__ != hipSuccess)                                                                  \
-      return b7_fail((c), e__ == hipErrorOutOfMemory ? B7_ERR_NOMEM : B7_ERR_HIP, "%s: %s", \
-                     #expr, hipGetErrorString(e__));                                        \
+// (the message names the call site, not the expression: the library's strings hold no internal constant names)
+#define B7_HIP(c, expr)                                                                          \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return b7_fail((c), e__ == hipErrorOutOfMemory ? B7_ERR_NOMEM : B7_ERR_HIP, "%s:%d: %s", \
+                     __FILE_NAME__, __LINE__, hipGetErrorString(e__));                           \
   } while (0)
 #define B7_TRY(expr)          \
   do {                        \

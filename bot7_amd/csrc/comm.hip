@@ -24,9 +24,13 @@
 Rccl &rccl() {
   static Rccl r;
   if (r.handle || !r.err.empty()) return r;
-  // B7_RCCL_LIB: another RCCL build, or (tests) a name that does not exist, to see the failure path without a host
-  // that lacks the library
+  // B7_RCCL_LIB (diagnostic build only): the tests' double for RCCL's transport, or a name that does not exist, to see the
+  // failure path without a host that lacks the library.  The shipped library resolves librccl by its SONAME and nothing else.
+#ifdef B7_DIAG
   const char *forced = getenv("B7_RCCL_LIB");
+#else
+  const char *forced = nullptr;
+#endif
   const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
   if (forced) r.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
   else

@@ -22,5 +22,5 @@ Rccl &rccl();
 #define B7_NCCL(c, r, expr)                                                                       \
   do {                                                                                            \
     ncclResult_t e__ = (expr);                                                                    \
-    if (e__ != ncclSuccess) return b7_fail((c), B7_ERR_COMM, "%s: %s", #expr, (r).GetErrorString(e__)); \
+    if (e__ != ncclSuccess) return b7_fail((c), B7_ERR_COMM, "RCCL call at %s:%d: %s", __FILE_NAME__, __LINE__, (r).GetErrorString(e__)); \
   } while (0)

@@ -27,7 +27,7 @@
 
 namespace {
 
-__constant__ double exp2_tab_dev[128];  // B7_EXP2_TAB, uploaded once per process (ensure_exp_table)
+__constant__ double exp2_tab_dev[128];  // b7_exp2_tab, uploaded once per process (ensure_exp_table)
 
 // ---- observation pre-scaling: zsc = z .* w (padded), zsh = (sum z^2 w)/2 ---------------------------------------
 // One wave per 64 observations: the rows are loaded and stored through an LDS tile (coalesced both ways; a thread
@@ -331,7 +331,7 @@ size_t ksx_lds_bytes(int dpad) {
 int ensure_exp_table(b7_ctx *c) {
   static bool done[64] = {false};
   if (c->device < 64 && done[c->device]) return B7_OK;
-  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_dev), B7_EXP2_TAB, sizeof(B7_EXP2_TAB)));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_dev), b7_exp2_tab, sizeof(b7_exp2_tab)));
   if (c->device < 64) done[c->device] = true;
   return B7_OK;
 }

@@ -587,8 +587,8 @@ int launch_append_finalize(b7_ctx *c, const double *krow, const double *lvec, co
 static int ensure_blr_tables(b7_ctx *c) {
   static bool done[64] = {false};
   if (c->device < 64 && done[c->device]) return B7_OK;
-  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_blr), B7_EXP2_TAB, sizeof(B7_EXP2_TAB), 0));
-  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_blr), B7_EXP2M1_TAB, sizeof(B7_EXP2M1_TAB), sizeof(B7_EXP2_TAB)));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_blr), b7_exp2_tab, sizeof(b7_exp2_tab), 0));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_blr), b7_exp2m1_tab, sizeof(b7_exp2m1_tab), sizeof(b7_exp2_tab)));
   if (c->device < 64) done[c->device] = true;
   return B7_OK;
 }

@@ -42,7 +42,7 @@ extern "C" int b7dbg_gs_stamps(unsigned long long *out) {
 namespace {
 using namespace b7diag;  // NB = 64, DLD, TLD, diag_core, diag_bystander
 
-__constant__ double exp2_tab_gs[128];  // B7_EXP2_TAB (ensure_gs_table)
+__constant__ double exp2_tab_gs[128];  // b7_exp2_tab (ensure_gs_table)
 
 constexpr int OLD = 33;         // row stride of the observation image [128][OLD] (32 columns, zero padded)
 constexpr int BUF = NB * DLD;   // one 64 x 66 image
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
 int ensure_gs_table(b7_ctx *c) {
   static bool done[64] = {false};
   if (c->device < 64 && done[c->device]) return B7_OK;
-  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_gs), B7_EXP2_TAB, sizeof(B7_EXP2_TAB)));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_gs), b7_exp2_tab, sizeof(b7_exp2_tab)));
   if (c->device < 64) done[c->device] = true;
   return B7_OK;
 }

@@ -145,11 +145,14 @@ int b7_group_create(b7_group **out, int n, const int *device_ids) {
     g->ctx.push_back(c);
   }
   const std::set<int> distinct(device_ids, device_ids + n);
-  // B7_GROUP_EXCHANGE: "host" merges on the host even across distinct devices; "rccl" issues the grouped all-reduce even when
-  // members share a device (real RCCL refuses that at ncclCommInitAll; the tests' in-process double accepts it, which is how
-  // the grouped branch runs with n > 1 on a one-GPU box)
+  // B7_GROUP_EXCHANGE: "host" merges on the host even across distinct devices; in the DIAGNOSTIC build "rccl" issues the
+  // grouped all-reduce even when members share a device (real RCCL refuses that at ncclCommInitAll; the tests' in-process
+  // double accepts it, which is how the grouped branch runs with n > 1 on a one-GPU box)
   const char *mode = getenv("B7_GROUP_EXCHANGE");
-  g->use_rccl = ((int)distinct.size() == n && !(mode && strcmp(mode, "host") == 0)) || (mode && strcmp(mode, "rccl") == 0);
+  g->use_rccl = (int)distinct.size() == n && !(mode && strcmp(mode, "host") == 0);
+#ifdef B7_DIAG
+  if (mode && strcmp(mode, "rccl") == 0) g->use_rccl = true;
+#endif
   if (g->use_rccl) {
     Rccl &r = rccl();
     ncclResult_t e = ncclSuccess;

@@ -26,7 +26,7 @@
 
 namespace {
 
-__constant__ double exp2_tab_kp[128];  // B7_EXP2_TAB (ensure_kp_table)
+__constant__ double exp2_tab_kp[128];  // b7_exp2_tab (ensure_kp_table)
 
 constexpr int KP_THREADS = 512;  // eight waves share one LDS copy of a fit; one workgroup per CU (two waves per SIMD)
 
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
 int ensure_kp_table(b7_ctx *c) {
   static bool done[64] = {false};
   if (c->device < 64 && done[c->device]) return B7_OK;
-  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_kp), B7_EXP2_TAB, sizeof(B7_EXP2_TAB)));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_kp), b7_exp2_tab, sizeof(b7_exp2_tab)));
   if (c->device < 64) done[c->device] = true;
   return B7_OK;
 }

@@ -24,7 +24,7 @@
 namespace {
 using namespace b7diag;  // NB = 64, DLD, TLD, diag_core
 
-__constant__ double exp2_tab_small[128];  // B7_EXP2_TAB (ensure_small_table)
+__constant__ double exp2_tab_small[128];  // b7_exp2_tab (ensure_small_table)
 
 constexpr int OLD = 33;  // row stride of the observation image [128][OLD] (32 columns, zero padded)
 constexpr int NLL_SMALL_LDS_DOUBLES = 128 * OLD + 3 * NB * DLD + 32 * TLD + 128 * 4 + 32 + 128 + 512;
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256)
 int ensure_small_table(b7_ctx *c) {
   static bool done[64] = {false};
   if (c->device < 64 && done[c->device]) return B7_OK;
-  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_small), B7_EXP2_TAB, sizeof(B7_EXP2_TAB)));
+  B7_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(exp2_tab_small), b7_exp2_tab, sizeof(b7_exp2_tab)));
   if (c->device < 64) done[c->device] = true;
   return B7_OK;
 }

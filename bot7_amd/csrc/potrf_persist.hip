@@ -399,7 +399,10 @@ __device__ void critical_path(const PArgs &a, const Flags &F, double *dsm, int *
       tile_from_lds(vx, X);
       tile_store_sc1(vx, a.dinv + (int64_t)p * NB * NB, NB);
     }
-    if (p != a.fault_panel) wg_publish(F.ready(p, p));
+#ifdef B7_DIAG
+    if (p != a.fault_panel)  // tests only (B7_PERSIST_FAULT): withhold one flag to exercise the time-out path
+#endif
+      wg_publish(F.ready(p, p));
     PST(p, 2);
     d2_t d1[8], d2[8];
     // what the prefetch did not get (its latency overlaps the store of L_pp issued behind it)
@@ -1147,7 +1150,8 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
 
 size_t persist_flag_words_host(int nb) { return persist_flag_words(nb); }
 
-// diagnostics (tools/persist_stamps.py): the stamps of the last persistent launch, [nb][8] then [njobs][4]
+// diagnostics (tools/persist_stamps.py; diagnostic build only): the stamps of the last persistent launch, [nb][8] then [njobs][4]
+#ifdef B7_DIAG
 extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_words, int *nb_out, int *njobs_out) {
   if (!c->pstamps.p) return B7_ERR_STATE;
   const int words = c->pjobs_nb * 8 + c->pjobs_n * 4;
@@ -1158,6 +1162,7 @@ extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_
                       hipMemcpyDeviceToHost));
   return B7_OK;
 }
+#endif
 
 // diagnostics: persistent launches of this context that timed out on a hand-off and were redone by the launch schedule
 extern "C" int b7dbg_persist_aborts(b7_ctx *c) { return c ? c->persist_aborts : -1; }

@@ -28,6 +28,14 @@ def orc():
     return o
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _diag_build():
+    """The diagnostic build of the library (A/B switches, fault injector, RCCL override: -DB7_DIAG) beside the shipped one; a
+    no-op when it is up to date (__graft_entry__.build() makes it)."""
+    from bot7_amd import build as B
+    return B.build_diag()
+
+
 @pytest.fixture(scope="session")
 def ctx():
     """A libbot7hip context on cuda:0.  Fails loudly (no skip, no fallback) when the GPU or the .so is missing."""

@@ -151,7 +151,7 @@ def test_slice_sampler_defaults_and_distribution():
 
 def test_missing_library_fails_loudly(monkeypatch):
     """No silent fallback: without the shared library the loader raises instead of computing elsewhere."""
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "_SO", os.path.join(ROOT, "bot7_amd", "no_such_libbot7hip.so"))
     with pytest.raises(bot7_amd.Bot7HipError) as e:
         _lib.load()

@@ -204,7 +204,7 @@ def test_inline_inverse_matches_separate_pass(ctx, orc, monkeypatch):
     import bot7_amd
     X_obs, Y, _, hyp = make_problem(ctx, orc, 6, 1100, 64, B.hartmann6)
     monkeypatch.setenv("B7_INVERSE_INLINE", "0")
-    ref = bot7_amd.Context(0)
+    ref = bot7_amd.Context(0, lib="diag")      # the switches exist in the diagnostic build only (tools/_build/libbot7hip_diag.so)
     monkeypatch.delenv("B7_INVERSE_INLINE")
     for c in (ctx, ref):
         c.profile_enable(True)
@@ -228,7 +228,7 @@ def test_cholesky_schedules_agree(ctx, orc, monkeypatch, env):
     X_obs, Y, _, hyp = make_problem(ctx, orc, 6, 700, 64, B.hartmann6)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    alt = bot7_amd.Context(0)
+    alt = bot7_amd.Context(0, lib="diag")
     for k in env:
         monkeypatch.delenv(k)
     ctx.gp_fit(X_obs, Y, **hyp)
@@ -1547,14 +1547,13 @@ def _two_schedules(monkeypatch):
     out = []
     for sched in ("1", "3"):
         monkeypatch.setenv("B7_POTRF_SCHED", sched)
-        out.append(bot7_amd.Context(0))
+        out.append(bot7_amd.Context(0, lib="diag"))
     monkeypatch.delenv("B7_POTRF_SCHED")
     return out
 
 
 def _aborts(c):
-    from bot7_amd import _lib
-    return _lib.load().b7dbg_persist_aborts(c._h)
+    return c._L.b7dbg_persist_aborts(c._h)
 
 
 @pytest.mark.parametrize("N,d,cols", [(2, 3, 1), (64, 6, 1), (100, 6, 1), (129, 6, 1), (256, 6, 7), (700, 32, 1),
@@ -1737,7 +1736,7 @@ def test_dpp_fused_multiply_add_equals_its_two_instruction_form(orc, monkeypatch
     for var in ("1", "2"):
         monkeypatch.setenv("B7_DIAG_VARIANT", var)
         monkeypatch.setenv("B7_POTRF_SCHED", "1")
-        ctxs.append(bot7_amd.Context(0))
+        ctxs.append(bot7_amd.Context(0, lib="diag"))
     monkeypatch.delenv("B7_DIAG_VARIANT")
     monkeypatch.delenv("B7_POTRF_SCHED")
     try:
@@ -1947,7 +1946,7 @@ def test_small_set_likelihood_kernel_equals_the_general_path_and_the_oracle(orc,
     no noise) must fall back and report the same jitter; N = 129 and d = 33 take the general path on their own."""
     import bot7_amd
     monkeypatch.setenv("B7_NLL_SMALL", "0")
-    general = bot7_amd.Context(0)
+    general = bot7_amd.Context(0, lib="diag")
     monkeypatch.delenv("B7_NLL_SMALL")
     small = bot7_amd.Context(0)
     rng = np.random.default_rng(31)
@@ -2063,7 +2062,7 @@ def test_one_block_padding_appends_and_crosses_to_two_blocks(ctx, orc):
     try:
         import subprocess
         import sys
-        code = ("import os, sys, numpy as np; sys.path.insert(0, %r); import bot7_amd; c = bot7_amd.Context(0);"
+        code = ("import os, sys, numpy as np; sys.path.insert(0, %r); import bot7_amd; c = bot7_amd.Context(0, lib='diag');"
                 "d = np.load(sys.argv[1]); c.grid_upload(d['Xh']); c.gp_fit(d['X'], d['Y'], d['ls'], float(d['amp']), float(d['noise']), float(d['mean']));"
                 "mu, var = c.gp_predict(); np.savez(sys.argv[2], mu=mu, var=var)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         import tempfile

@@ -317,7 +317,7 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
             "try:\n    _lib.comm_unique_id()\n    print('no error')\n"
             "except _lib.Bot7HipError as e:\n    print('code', e.code, str(e))\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
-                         env=dict(os.environ, B7_RCCL_LIB="/nonexistent/librccl-not-here.so"))
+                         env=dict(os.environ, B7_RCCL_LIB="/nonexistent/librccl-not-here.so", BOT7HIP_LIB=_diag_lib()))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "code -7" in out.stdout and "librccl-not-here" in out.stdout, out.stdout
 
@@ -391,6 +391,13 @@ def test_group_with_more_members_than_rows_and_shards_that_run_empty(ctx, orc):
 
 
 # ---- several PROCESSES, one GPU: the per-process communicator path with a test double for RCCL's transport ----------------
+def _diag_lib():
+    """The DIAGNOSTIC build of the library (-DB7_DIAG: B7_RCCL_LIB, B7_GROUP_EXCHANGE=rccl and the A/B switches exist there only);
+    the worker processes of this file use it as THE library (BOT7HIP_LIB)."""
+    from bot7_amd import build as B
+    return B.build_diag()
+
+
 def _stub_lib():
     """tests/stub/rccl_shm_stub.cpp -> tests/stub/_build/librccl_shm_stub.so (tools/build_stub.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -416,7 +423,7 @@ def test_processes_sharing_the_gpu_run_the_trial_loop_through_the_communicator_p
     one = dist.ShardedScorer(ctx, grid.shape[0], 0, 1)
     xs1, ys1, best1 = _run_bot(one, ctx, trials, nSamples=3, sample=sample)
     left1 = ctx.grid_download()
-    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), PYTHONPATH=ROOT, B7_TEST_SAMPLE="1" if sample else "0")
+    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), BOT7HIP_LIB=_diag_lib(), PYTHONPATH=ROOT, B7_TEST_SAMPLE="1" if sample else "0")
     ident = ("b7stub_%d_%d" % (os.getpid(), world)).encode().hex()
     outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_comm_worker.py"), str(r), str(world), ident, str(trials),
@@ -456,7 +463,7 @@ def test_grouped_rccl_branch_runs_with_virtual_ranks(tmp_path):
     import json
     import subprocess
     out = str(tmp_path / "group.json")
-    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), B7_GROUP_EXCHANGE="rccl", PYTHONPATH=ROOT)
+    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), B7_GROUP_EXCHANGE="rccl", BOT7HIP_LIB=_diag_lib(), PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_group_worker.py"), out, "2", "3", "8"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]

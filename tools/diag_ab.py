@@ -11,7 +11,7 @@ ctxs = {}
 for st in settings:
     kv = dict(item.split("=") for item in st.split(",") if item)
     os.environ.update(kv)
-    ctxs[st] = bot7_amd.Context(0)
+    ctxs[st] = bot7_amd.Context(0, lib="diag")  # the switches live in the diagnostic build (python -m bot7_amd.build --diag)
     for k in kv:
         del os.environ[k]
 d, N = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 2048

@@ -14,7 +14,7 @@ from oracle import gp  # noqa: E402
 ctxs = {}
 for flag in ("1", "0"):
     os.environ["B7_NLL_SMALL"] = flag
-    ctxs[flag] = bot7_amd.Context(0)
+    ctxs[flag] = bot7_amd.Context(0, lib="diag")  # the switches live in the diagnostic build (python -m bot7_amd.build --diag)
 del os.environ["B7_NLL_SMALL"]
 for d, N, fn in ((2, 24, benchmarks.braninhoo), (6, 64, benchmarks.hartmann6), (6, 100, benchmarks.hartmann6), (32, 128, benchmarks.ackley)):
     X = ctxs["1"].grid_sobol(N, d, 2)

@@ -21,11 +21,12 @@ def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     for lib, define in ((LIB, "-DB7_NLL_STAMP"), (POISON, "-DB7_NLL_POISON")):
         objs = []
-        for src in B.SOURCES:
-            obj = os.path.join(B.BUILD, src.replace(".hip", ".o"))
+        B.build_diag()
+        for src in B.SOURCES + B.DIAG_ONLY_SOURCES:   # round 3's kernel lives in the diagnostic build (B7_NLL_SMALL=2 selects it)
+            obj = os.path.join(B.BUILD, ("diag_" if (B._mentions_diag(src) or src in B.DIAG_ONLY_SOURCES) else "") + src.replace(".hip", ".o"))
             if src == "nll_small.hip":
                 obj = lib.replace(".so", ".o")
-                subprocess.check_call([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + [define, "-c", os.path.join(B.CSRC, src), "-o", obj])
+                subprocess.check_call([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + [define, "-DB7_DIAG", "-c", os.path.join(B.CSRC, src), "-o", obj])
             objs.append(obj)
         subprocess.check_call([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs +
                               ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
@@ -34,6 +35,7 @@ def build():
 
 def run():
     os.environ["BOT7HIP_LIB"] = LIB
+    os.environ["B7_NLL_SMALL"] = "2"
     import numpy as np
     import bot7_amd
     ctx = bot7_amd.Context(0)

@@ -10,7 +10,7 @@ from harness import benchmarks  # noqa: E402
 ctxs = {}
 for sched in ("1", "3"):
     os.environ["B7_POTRF_SCHED"] = sched
-    ctxs[sched] = bot7_amd.Context(0)
+    ctxs[sched] = bot7_amd.Context(0, lib="diag")  # the switches live in the diagnostic build (python -m bot7_amd.build --diag)
 del os.environ["B7_POTRF_SCHED"]
 d = 32
 for N in [int(a) for a in sys.argv[1:]] or [100, 256, 700, 1024, 2048]:

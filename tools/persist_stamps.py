@@ -17,7 +17,7 @@ from harness import benchmarks  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 d = 32
-c = bot7_amd.Context(0)
+c = bot7_amd.Context(0, lib="diag")  # the switches live in the diagnostic build (python -m bot7_amd.build --diag)
 X = c.grid_sobol(N, d, 2)
 Y = benchmarks.ackley(X)
 amp = float(np.var(Y))

@@ -9,7 +9,7 @@ groups = [int(g) for g in os.environ.get("GROUPS", "1,2,4,8").split(",")]
 ctxs = {}
 for g in groups:
     os.environ["B7_POTRF_GROUP"] = str(g)
-    ctxs[g] = bot7_amd.Context(0)
+    ctxs[g] = bot7_amd.Context(0, lib="diag")  # the switches live in the diagnostic build (python -m bot7_amd.build --diag)
 d, N = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 X = ctxs[groups[0]].grid_sobol(N, d, 1)
 Y = benchmarks.ackley(X)

@@ -13,7 +13,7 @@ from harness import benchmarks  # noqa: E402
 for N, d, fn in ((25, 2, benchmarks.braninhoo), (100, 6, benchmarks.hartmann6)):
     for flag in ("1", "0"):
         os.environ["B7_NLL_SMALL"] = flag
-        c = bot7_amd.Context(0)
+        c = bot7_amd.Context(0, lib="diag")  # the switches live in the diagnostic build (python -m bot7_amd.build --diag)
         X = c.grid_sobol(N, d, 2)
         Y = fn(X)
         m = bot7_amd.models.gp_regressor({"sample": True, "nBurnin": 5, "seed": 3}, context=c)

@@ -14,7 +14,7 @@ def make(env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        return bot7_amd.Context(0)
+        return bot7_amd.Context(0, lib="diag" if env else None)   # the switches exist in the diagnostic build only
     finally:
         for k, v in old.items():
             if v is None:
