@@ -71,6 +71,13 @@ def parse():
                          "may share one GPU and exchange through torch.distributed on the CPU (rehearsal of N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=131072, help="candidates in the bounded CPU-baseline sample")
     ap.add_argument("--workspace-mib", type=int, default=0, help="K(X*,X) chunk workspace (default: the library's)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "group", "ranks"],
+                    help="N > 1: 'ranks' = one process per GPU (torch.distributed.run launches them; b7_comm_*), 'group' = ONE process "
+                         "driving N GPUs (b7_group_*: the reference's own layout, bots/abstract.lua:155-169); auto: ranks when a "
+                         "launcher set RANK, else group")
+    ap.add_argument("--virtual-ranks", action="store_true",
+                    help="group layout on fewer than N devices: members share device 0 (rehearsal on a one-GPU box; RCCL refuses "
+                         "that, the exchange is merged on the host unless the diagnostic build + test double force the grouped call)")
     return ap.parse_args()
 
 
@@ -339,8 +346,124 @@ def run_default(args):
     ctx.close()
 
 
+def run_group(args):
+    """python bench.py --gpus N with no launcher: ONE process drives N GPUs (b7_group_*), the layout the reference itself has
+    (one LuaJIT process, bots/abstract.lua:155-169).  Candidates are sharded over the members by contiguous row ranges, the fit
+    is replicated, every member's work is enqueued without a host wait in between, and the winners are combined by ONE grouped
+    ncclAllReduce (ncclCommInitAll) when the devices are distinct.  Weak scaling: --candidates rows per GPU."""
+    import bot7_amd
+    from harness import benchmarks
+    d, N, M_default, obj_name, score = WORKLOADS[args.workload]
+    if obj_name == "dngo":
+        sys.exit("bench.py: the single-process group has no DNGO branch; launch cfg5 with torch.distributed.run (--layout ranks)")
+    G = args.gpus
+    M = args.candidates or M_default
+    M_total = M * G
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev >= G and not args.virtual_ranks:
+        devices = list(range(G))
+    elif args.virtual_ranks:
+        devices = [0] * G
+    else:
+        sys.exit("bench.py --gpus %d: %d device(s) visible; pass --virtual-ranks to rehearse the group layout on one" % (G, ndev))
+    lib = "diag" if os.environ.get("B7_GROUP_EXCHANGE") == "rccl" else None   # forcing the grouped call for virtual ranks: diagnostic build
+    g = bot7_amd.Group(devices, lib=lib)
+    ginfo = g.info()
+    if args.workspace_mib:
+        g.set_workspace(args.workspace_mib << 20)
+    # inputs (SURVEY 8d): the pool on the group, the observation rows deleted from the union; observations via a scratch context
+    s_ = (M_total + N) // N
+    tmp = bot7_amd.Context(devices[0], lib=lib)
+    gen1 = (lambda first: tmp.grid_sobol(1, d, SOBOL_SKIP + first)) if d < 40 else (lambda first: tmp.grid_random(1, d, seed=1, row_offset=first))
+    X_obs = np.concatenate([gen1(k * s_) for k in range(N)], axis=0)
+    tmp.close()
+    if d < 40:
+        g.grid_sobol(M_total + N, d, SOBOL_SKIP)
+    else:
+        g.grid_random(M_total + N, d, seed=1)
+    g.grid_remove_rows([k * s_ + 1 for k in range(N)], want_rows=False)
+    assert g.grid_shape()[0] == M_total
+    Y = benchmarks.registry[obj_name](X_obs)
+    amp = float(np.var(Y))
+    hyp = {"lenscale_sq": np.full(d, d / 8.0), "amp": amp, "noise": 1e-4 * amp, "mean": float(np.mean(Y))}
+    g.gp_set_data(X_obs, Y)
+    spec = {"score": "ei", "fmin": [float(Y.min())], "tradeoff": 0.0} if score == "ei" else {"score": "cb"}
+    hyps = [dict(hyp, lenscale_sq=hyp["lenscale_sq"] * (1.0 + 0.05 * s_i)) for s_i in range(args.samples)]
+
+    def fence():
+        for m in g.members:
+            m.sync()
+        torch.cuda.synchronize()
+
+    def timed(steps):
+        gc.collect()
+        gc.disable()
+        try:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b = g.eval_nominate(hyps, **spec)
+            fence()
+            return time.perf_counter() - t0, b
+        finally:
+            gc.enable()
+
+    for _ in range(args.warmup):
+        g.eval_nominate(hyps, **spec)
+    m0 = g.members[0]
+    m0.profile_enable(True)
+    m0.profile_reset()
+    elapsed, best = timed(args.steps)
+    m0.profile_enable(False)
+    elapsed_plain, best_plain = timed(args.steps)
+    assert best_plain == best
+    phases = {}
+    for ph in ("prep", "kxx", "potrf", "trtri", "alpha", "ksx", "post", "kpost", "score", "argmax", "exchange"):
+        ms, n = m0.profile_get(ph)
+        if n:
+            phases[ph] = {"ms_total": round(ms, 4), "launches": n, "ms_avg": round(ms / n, 5)}
+    post = phases.get("post") or phases.get("kpost") or {"ms_total": 0.0, "launches": 0}
+    M0 = g.grid_shape()[2][1] - g.grid_shape()[2][0]          # member 0's rows
+    lps = max(1, post["launches"] // max(1, args.steps))
+    rows_per_launch = M0 * args.samples / lps
+    flops = rows_per_launch * float(N) * float(N)
+    t_post = post["ms_total"] / post["launches"] * 1e-3 if post["launches"] else float("nan")
+    achieved = flops / t_post / 1e12 if post["launches"] else float("nan")
+    line = {
+        "metric": "EI candidates scored/sec at N=2048,d=32" if args.workload == "metric" else "%s candidates scored/sec (%s)" % (score.upper(), args.workload),
+        "value": args.steps * M_total * args.samples / elapsed, "hyper_samples_per_step": args.samples, "unit": "candidates/s",
+        "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_without_phase_events": elapsed_plain / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %s d=%d, N=%d obs (strided pick from the pool, SURVEY 8d), %d candidates per GPU (%d total), %s, %d hyper "
+                               "sample(s) per step = fit + K(X*,X) + posterior mean/var + score:add per member, score:div + arg-max + ONE exchange"
+                               % (args.workload, obj_name, d, N, M, M_total, score.upper(), args.samples),
+                   "d": d, "n_obs": N, "candidates_per_gpu": M, "candidates_total": M_total, "score": score,
+                   "parallelism": "single-process group x%d (b7_group_*: one host process drives every GPU, the reference's own layout); candidate-sharded, "
+                                  "fit replicated, one exchange per nomination: %s"
+                                  % (G, ("grouped ncclAllReduce (ncclCommInitAll over %d %s)" % (G, "distinct devices" if len(set(devices)) == G else
+                                                                                                    "VIRTUAL ranks on one device through the test double"))
+                                     if ginfo["uses_rccl"] else "records merged on the host (members share a device: RCCL refuses that)"),
+                   "layout": "group", "devices": devices, "rccl_ranks": G if ginfo["uses_rccl"] else 0,
+                   "device": m0.device_info()["name"]},
+        "roofline": {"bound": "mfma", "kernel": "posterior variance kernel of member 0", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS if achieved == achieved else None, "traffic": None,
+                     "flops_per_launch": flops, "avg_launch_ms": t_post * 1e3},
+        "phases_member0": phases, "best": {"value": best[0], "index1": best[1]},
+        "step_api": "b7_group_eval_nominate (one call per step; one host wait per member)",
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line))
+    sys.stdout.flush()
+    g.close()
+
+
 def main():
     args = parse()
+    no_launcher = "RANK" not in os.environ
+    if args.workload != "default" and args.gpus > 1 and (args.layout == "group" or (args.layout == "auto" and no_launcher)):
+        return run_group(args)
     if args.workload == "default":
         if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
             sys.exit("bench.py --workload default runs on one GPU (a latency-bound trial loop)")
@@ -349,8 +472,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        if world == 1 and args.gpus > 1:   # --layout ranks without a launcher
+            sys.exit("bench.py --gpus %d --layout ranks must be launched with torch.distributed.run (one process per GPU); "
+                     "without a launcher the default is the single-process group" % args.gpus)
         args.gpus = world
     rccl = args.backend in ("rccl", "nccl")
 
@@ -439,6 +563,11 @@ def main():
                 # bots/bayesopt.lua:65-66 + :96 over models/dngo.lua:155-175 as ONE call: features of the observations,
                 # the Bayesian linear head, features of every candidate (recomputed each step, as the reference does),
                 # mean / variance, EI, the (global) arg-max
+                if samples > 1:   # models/dngo.lua:109 'marginalize': S heads over the same features, one call
+                    al = alpha_p * (1.0 + 0.1 * np.arange(samples))
+                    be = beta * (1.0 + 0.05 * np.arange(samples))
+                    return ctx.blr_eval_nominate_marg(Wn, bn, "Tanh", X_obs, Y, al, be, np.full(samples, ymean), score="ei", fmin=fmin,
+                                                      global_row_offset=shard.lo)[:2]
                 return ctx.blr_eval_nominate(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean, score="ei", fmin=fmin,
                                              global_row_offset=shard.lo)
             ctx.blr_fit_x(Wn, bn, "Tanh", X_obs, Y, alpha_p, beta, ymean)
@@ -499,7 +628,7 @@ def main():
     # dominant kernel: post_kernel.  Algorithmic flops per launch = rows_in_launch * Npad^2 (triangular L^-1
     # exploited: N^2/2 multiply-adds per candidate); rows per launch = M / launches-per-step.
     post_launches_per_step = max(1, post["launches"] // max(1, args.steps))
-    n_samples = 1 if obj_name == "dngo" else args.samples
+    n_samples = args.samples
     rows_per_launch = M * n_samples / post_launches_per_step
     n_eff = 128 if obj_name == "dngo" else N   # DNGO: the "observations" of the variance GEMM are the 50 -> 128 padded features
     flops_per_launch = rows_per_launch * float(n_eff) * float(n_eff)

@@ -23,7 +23,7 @@ SYMBOLS = [
     "b7_grid_colrange", "b7_grid_apply_onesided", "b7_grid_random_torch", "b7_torch_rand",
     "b7_gp_default_opts", "b7_gp_set_opts", "b7_gp_fit", "b7_gp_set_data", "b7_gp_fit_hyp", "b7_gp_predict_hyp", "b7_gp_nll_batch", "b7_chol", "b7_gp_predict", "b7_gp_predict_at", "b7_gp_fantasize", "b7_gp_append", "b7_gp_download",
     "b7_blr_basis", "b7_blr_features", "b7_blr_fit", "b7_blr_fit_x", "b7_blr_predict", "b7_score_reset", "b7_score_ei", "b7_score_cb", "b7_score_finish",
-    "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global", "b7_eval_nominate", "b7_blr_eval_nominate",
+    "b7_comm_pick_winner", "b7_comm_unique_id", "b7_comm_init", "b7_comm_info", "b7_comm_destroy", "b7_comm_allreduce_f64", "b7_score_finish_global", "b7_eval_nominate", "b7_blr_eval_nominate", "b7_blr_eval_nominate_marg",
     "b7_nominate_commit", "b7_shard_commit_rule", "b7_exchange_info",
     "b7_group_create", "b7_group_destroy", "b7_group_last_error", "b7_group_info", "b7_group_ctx", "b7_group_set_workspace", "b7_group_gp_set_opts",
     "b7_group_grid_sobol", "b7_group_grid_random", "b7_group_grid_onesided", "b7_group_grid_upload", "b7_group_grid_shape", "b7_group_grid_download",
@@ -141,6 +141,8 @@ def load(which=None):
                                    vp, vp]),
         "b7_blr_eval_nominate": (i32, [vp, C.POINTER(Mlp), vp, vp, i32, dbl, dbl, dbl, C.POINTER(ScoreSpec), i64, C.POINTER(dbl),
                                        C.POINTER(i64), C.POINTER(dbl)]),
+        "b7_blr_eval_nominate_marg": (i32, [vp, C.POINTER(Mlp), vp, vp, i32, i32, vp, vp, vp, C.POINTER(ScoreSpec), i64, C.POINTER(dbl),
+                                            C.POINTER(i64), vp, C.POINTER(dbl)]),
         "b7_grid_random_torch": (i32, [vp, i64, i32, C.c_uint64, i32, vp, vp, vp]),
         "b7_torch_rand": (i32, [C.c_uint64, i64, i32, vp]),
         "b7_grid_colrange": (i32, [vp, vp, vp]),
@@ -547,6 +549,27 @@ class Context(object):
                                               C.byref(i), C.byref(j)))
         self.fit_token += 1
         return (v.value, i.value, j.value) if want_jitter else (v.value, i.value)
+
+    def blr_eval_nominate_marg(self, weights, biases, activation, X0, Y0, alphas, betas, means, score="ei", fmin=None,
+                               tradeoff=None, upper=False, sign=-1.0, global_row_offset=0, want_nll=False):
+        """bayesopt:eval's DNGO branch with the head's hypers marginalised (models/dngo.lua:109,174): S samples (alpha, beta, mean),
+        S heads over the same features, score:add per sample, score:div(S), score:max(1).  Returns (value, 1-based global index,
+        jitter flag[, nll per sample])."""
+        net = self._mlp(weights, biases, activation)
+        X = _f64(X0)
+        Y = _f64(Y0).ravel()
+        a, b, m = (np.ascontiguousarray(_f64(v).ravel()) for v in (alphas, betas, means))
+        S = a.size
+        if b.size != S or m.size != S:
+            raise Bot7HipError(-1, "alphas, betas and means must have the same length")
+        spec, fm = self._pack_spec(score, fmin, tradeoff, upper, sign)
+        nll = np.empty(S, dtype=np.float64) if want_nll else None
+        v, i, jit = C.c_double(), C.c_int64(), C.c_double()
+        self._ck(self._L.b7_blr_eval_nominate_marg(self._h, C.byref(net), _ptr(X), _ptr(Y), X.shape[0], S, _ptr(a), _ptr(b), _ptr(m),
+                                                   C.byref(spec), int(global_row_offset), C.byref(v), C.byref(i), _ptr(nll),
+                                                   C.byref(jit)))
+        self.fit_token += 1
+        return (v.value, i.value, jit.value, nll) if want_nll else (v.value, i.value, jit.value)
 
     def blr_predict(self, download=True):
         M, _ = self.grid_shape()

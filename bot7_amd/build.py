@@ -2,7 +2,8 @@
 
     python -m bot7_amd.build [--force]
 
-One object per .hip translation unit (parallel), then one shared library next to this file.  The library
+One object per .hip translation unit (parallel), then one shared library next to this file, linked -Bsymbolic: its internal
+calls bind to its own definitions, so that a second build of the library (the diagnostic one) can live in the same process.  The library
 links only against the HIP runtime (libamdhip64.so.7); no torch, no rocBLAS/rocSOLVER; librccl.so.1 is dlopen'ed
 at the first b7_comm_* call (csrc/comm.hip).
 """
@@ -64,7 +65,7 @@ def build_diag(verbose=False):
     objs = [res[s][0] if s in res else os.path.join(BUILD, s.replace(".hip", ".o")) for s in SOURCES + DIAG_ONLY_SOURCES]
     if any(ch for _, ch in res.values()) or _stale(DIAG_OUT, objs):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", DIAG_OUT] + objs +
-                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
         if verbose:
             print("built", DIAG_OUT)
     return DIAG_OUT
@@ -144,7 +145,7 @@ def build(force=False, verbose=False):
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or _stale(OUT, objs):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs +
-                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
         if verbose:
             print("built", OUT)
     return OUT

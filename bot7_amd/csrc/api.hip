@@ -168,7 +168,7 @@ int b7_create(b7_ctx **out, int device_id) {
   if (const char *pv = getenv("B7_DIAG_VARIANT")) c->diag_variant = atoi(pv);  // 0 rsqrt chain, 1 DPP-fused (default), 2 its mov+fma reference
   if (const char *pv = getenv("B7_NPAD_SMALL")) c->npad_small = atoi(pv) != 0;  // 0: pad N <= 64 (and <= 64 basis features) to 128 as N > 64
   if (const char *pv = getenv("B7_POTRF_SMALL")) c->potrf_small = atoi(pv) != 0;
-  if (getenv("B7_POTRF_SCHED") || getenv("B7_DIAG_VARIANT") || getenv("B7_INVERSE_INLINE")) c->potrf_small = false;  // an explicit schedule is an A/B arm
+  if (getenv("B7_POTRF_SCHED") || getenv("B7_DIAG_VARIANT") || getenv("B7_INVERSE_INLINE")) c->potrf_small = c->fit_small = false;  // an explicit schedule is an A/B arm of the general path
   if (const char *pv = getenv("B7_BLR_SMALL")) c->blr_small = atoi(pv) != 0;  // 0: the head of b7_blr_eval_nominate through the general launches
   if (const char *pv = getenv("B7_INVERSE_INLINE")) c->inverse_inline = atoi(pv);  // 0 never, 1 up to N = 8192, 2 always
   if (const char *pv = getenv("B7_POTRF_SCHED")) c->potrf_sched = atoi(pv);  // 0 pairs, 1 one panel at a time up to N = 4096, 2 always
@@ -1892,6 +1892,198 @@ int b7_blr_eval_nominate(b7_ctx *c, const b7_mlp *net, const double *X0, const d
     rc = redo();
   }
   if (rc == B7_OK) rc = exch_local(c, 1.0, global_row_offset, rank, world, true);
+  const std::string own = c->err;
+  if (rc != B7_OK) B7_TRY(exch_fail_record(c, rank, world, rc));
+  B7_TRY(exch_allreduce(c));
+  B7_TRY(exch_fetch(c, 0, world));
+  B7_HIP(c, hipStreamSynchronize(c->stream));
+  if (rc != B7_OK) {
+    exch_forget(c);
+    c->err = own;
+    return rc;
+  }
+  return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
+}
+
+// ---- the same with the head's hypers marginalised (models/dngo.lua:109,174) -------------------------------------------------
+// S heads over the same features.  z <= 64 features (the usual DNGO head): everything is enqueued without a host wait -- features
+// of the observations, the S heads as S workgroups of ONE launch (blr_small.hip), features of the candidates, the S means (one
+// batched matrix-vector launch), the S variances (one launch of the posterior kernel over the shared features), and score:add x S +
+// div + arg-max + record fused in one launch.  Wider heads, or a failed pivot: head by head through b7_blr_fit_x.
+static int blr_marg_slow(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, int S, const double *ap,
+                         const double *bt, const double *mn, int z, const b7_score_spec *spec, double *nll_out) {
+  const int zpad = npad_of(c, z);
+  c->pend.on = false;
+  B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
+  B7_TRY(launch_fill(c, (double *)c->acc.p, c->M, 0.0));
+  c->acc_fresh = false;
+  c->acc_valid = true;
+  for (int s = 0; s < S; ++s) {
+    B7_TRY(b7_blr_fit_x(c, net, X0, Y0, N, ap[s], bt[s], mn[s], nll_out ? nll_out + s : nullptr));   // synchronous, jitter schedule included
+    if (s == 0) {
+      B7_TRY(feat_alloc(c, c->M, z));
+      B7_TRY(launch_mlp_forward(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p, net->dims,
+                                net->n_layers, net->activation, (double *)c->feat.p, zpad));
+    }
+    c->Mfeat = c->M;
+    B7_TRY(b7_ensure(c, c->mu, sizeof(double) * (size_t)c->M));
+    B7_TRY(b7_ensure(c, c->var, sizeof(double) * (size_t)c->M));
+    B7_TRY(launch_gemv_rows(c, (const double *)c->feat.p, c->Npad, (const double *)c->alpha.p, c->Npad, c->mean, 0, c->M, c->M,
+                            (double *)c->mu.p));
+    B7_TRY(launch_post(c, (const double *)c->feat.p, 0, round_up(c->M, B7_MROWS), c->M, (double *)c->var.p));
+    double *fd = nullptr;
+    if (spec->kind == B7_SCORE_EI) {
+      B7_TRY(stage_fmin(c, spec->fmin, &fd));
+      B7_TRY(launch_ei(c, (const double *)c->mu.p, (const double *)c->var.p, fd, spec->tradeoff, c->M, 1, (double *)c->acc.p, true));
+    } else {
+      B7_TRY(launch_cb(c, (const double *)c->mu.p, (const double *)c->var.p, spec->tradeoff, spec->upper, spec->sign, c->M, 1,
+                       (double *)c->acc.p, true));
+    }
+  }
+  c->predicted = true;
+  c->Mpred = c->M;
+  return B7_OK;
+}
+
+static int blr_marg_fast(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, int S, const double *ap,
+                         const double *bt, const double *mn, int z, const b7_score_spec *spec, bool want_terms) {
+  const int d = net->dims[0];
+  const size_t up_doubles = (size_t)N * d + (size_t)N + 5 * (size_t)S;   // [X0 | y | S alpha | S beta | S mean | S zeros | S 1/beta]
+  B7_TRY(b7_ensure(c, c->tmpmu, sizeof(double) * (up_doubles + (size_t)N * z)));
+  B7_TRY(b7_ensure(c, c->bL, sizeof(double) * (size_t)S * 64 * 64));
+  B7_TRY(b7_ensure(c, c->bLinv, sizeof(double) * (size_t)S * 64 * 64));
+  B7_TRY(b7_ensure(c, c->balpha, sizeof(double) * (size_t)S * 64));
+  B7_TRY(b7_ensure(c, c->bresid, sizeof(double) * (size_t)S * 64));
+  B7_TRY(b7_ensure(c, c->binfo, sizeof(int) * 4 * (size_t)S));
+  B7_TRY(b7_ensure(c, c->bterms, sizeof(double) * 3 * (size_t)S + 64));
+  B7_TRY(b7_ensure(c, c->bmu, sizeof(double) * (size_t)S * c->M));
+  B7_TRY(b7_ensure(c, c->bvar, sizeof(double) * (size_t)S * c->M));
+  B7_TRY(b7_ensure(c, c->acc, sizeof(double) * (size_t)c->M));
+  B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
+  // pinned, device-mapped block for the reports and the evidence's terms: [S][4] ints | [S][3] doubles
+  const size_t rep_bytes = 16 * (size_t)S, term_bytes = sizeof(double) * 3 * (size_t)S;
+  if (c->pin_eval_bytes < rep_bytes + term_bytes) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->pin_eval) (void)hipHostFree(c->pin_eval);
+    c->pin_eval = nullptr;
+    c->pin_eval_bytes = 0;
+    B7_HIP(c, hipHostMalloc(&c->pin_eval, 2 * (rep_bytes + term_bytes), hipHostMallocMapped));
+    B7_HIP(c, hipHostGetDevicePointer(&c->pin_eval_dev, c->pin_eval, 0));
+    c->pin_eval_bytes = 2 * (rep_bytes + term_bytes);
+  }
+  if (c->pin_blr_bytes < sizeof(double) * up_doubles) {
+    B7_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->pin_blr) (void)hipHostFree(c->pin_blr);
+    c->pin_blr = nullptr;
+    c->pin_blr_bytes = 0;
+    B7_HIP(c, hipHostMalloc(&c->pin_blr, 2 * sizeof(double) * up_doubles, hipHostMallocDefault));
+    c->pin_blr_bytes = 2 * sizeof(double) * up_doubles;
+  }
+  c->have_data = false, c->fitted = false, c->predicted = false;
+  c->N = z, c->Npad = 64, c->ycols = 1, c->yld = 1, c->model_kind = 1, c->amp = 0.0;
+  double *stage = static_cast<double *>(c->pin_blr);
+  memcpy(stage, X0, sizeof(double) * (size_t)N * d);
+  memcpy(stage + (size_t)N * d, Y0, sizeof(double) * N);
+  double *hs = stage + (size_t)N * d + N;
+  for (int s = 0; s < S; ++s) hs[s] = ap[s], hs[S + s] = bt[s], hs[2 * S + s] = mn[s], hs[3 * S + s] = 0.0, hs[4 * S + s] = 1.0 / bt[s];
+  double *xdev = (double *)c->tmpmu.p, *ydev = xdev + (size_t)N * d, *hdev = ydev + N, *zdev = hdev + 5 * (size_t)S;
+  B7_HIP(c, hipMemcpyAsync(xdev, stage, sizeof(double) * up_doubles, hipMemcpyHostToDevice, c->stream));
+  B7_TRY(launch_mlp_forward(c, xdev, N, d, (const double *)c->netbuf.p, net->dims, net->n_layers, net->activation, zdev, z));
+  int *reports = static_cast<int *>(c->pin_eval);
+  memset(reports, 0xff, rep_bytes);
+  B7_TRY(launch_blr_heads_small(c, S, zdev, N, z, z, ydev, hdev, (double *)c->bL.p, (double *)c->bLinv.p, (double *)c->balpha.p,
+                                (double *)c->bresid.p, (int *)c->binfo.p, static_cast<int *>(c->pin_eval_dev), (double *)c->bterms.p));
+  if (want_terms)
+    B7_HIP(c, hipMemcpyAsync(static_cast<char *>(c->pin_eval) + rep_bytes, c->bterms.p, term_bytes, hipMemcpyDeviceToHost, c->stream));
+  B7_TRY(feat_alloc(c, c->M, z));
+  B7_TRY(launch_mlp_forward(c, (const double *)c->grid[c->grid_cur].p, c->M, c->d, (const double *)c->netbuf.p, net->dims,
+                            net->n_layers, net->activation, (double *)c->feat.p, 64));
+  B7_TRY(launch_gemv_rows_batch(c, S, (const double *)c->feat.p, 64, (const double *)c->balpha.p, 64, 64, hdev + 2 * (size_t)S, c->M,
+                                (double *)c->bmu.p, c->M));
+  B7_TRY(launch_post_heads(c, S, (const double *)c->bLinv.p, (const double *)c->feat.p, round_up(c->M, B7_MROWS), c->M,
+                           (double *)c->bvar.p, c->M, hdev + 3 * (size_t)S, hdev + 4 * (size_t)S));
+  double *fd = nullptr;
+  if (spec->kind == B7_SCORE_EI) B7_TRY(stage_fmin(c, spec->fmin, &fd));
+  c->acc_fresh = true;
+  c->acc_valid = true;
+  c->pend.on = true;
+  c->pend.kind = spec->kind, c->pend.S = S, c->pend.upper = spec->upper;
+  c->pend.mu = (const double *)c->bmu.p, c->pend.var = (const double *)c->bvar.p, c->pend.fd = fd;
+  c->pend.stride = c->M, c->pend.tradeoff = spec->tradeoff, c->pend.sign = spec->sign;
+  return B7_OK;
+}
+
+int b7_blr_eval_nominate_marg(b7_ctx *c, const b7_mlp *net, const double *X0, const double *Y0, int N, int S, const double *ap,
+                              const double *bt, const double *mn, const b7_score_spec *spec, int64_t global_row_offset,
+                              double *best_val, int64_t *best_idx1, double *nll_out, double *jitter_used) {
+  if (!c) return B7_ERR_INVALID;
+  if (c->group) return b7_fail(c, B7_ERR_STATE, "blr_eval_nominate_marg: this context belongs to a group");
+  const bool exchange = c->comm && c->comm_world > 1;
+  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  if (jitter_used) *jitter_used = 0.0;
+  int rc = B7_OK, z = 0;
+  if (!X0 || !Y0 || N < 1 || S < 1 || !ap || !bt || !mn || !spec) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate_marg: bad arguments");
+  else if (spec->kind != B7_SCORE_EI && spec->kind != B7_SCORE_CB) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate_marg: unknown score kind %d", spec->kind);
+  else if (spec->kind == B7_SCORE_EI && !spec->fmin) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate_marg: EI needs fmin");
+  else if (global_row_offset < 0) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate_marg: negative row offset");
+  else if (c->M == 0 && !exchange) rc = b7_fail(c, B7_ERR_STATE, "blr_eval_nominate_marg: no candidate grid on this context");
+  for (int s = 0; rc == B7_OK && s < S; ++s)
+    if (!(ap[s] > 0.0) || !(bt[s] > 0.0)) rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate_marg: precisions must be > 0 (sample %d)", s);
+  if (rc == B7_OK) rc = hipSetDevice(c->device) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "hipSetDevice failed");
+  if (rc == B7_OK) rc = upload_net(c, net, &z);
+  if (rc == B7_OK && z > 256) rc = b7_fail(c, B7_ERR_UNSUPPORTED, "blr: basis width %d > 256", z);
+  if (rc == B7_OK && c->M > 0 && net->dims[0] != c->d)
+    rc = b7_fail(c, B7_ERR_INVALID, "blr_eval_nominate_marg: network input width %d != grid dims %d", net->dims[0], c->d);
+  const bool fast = rc == B7_OK && z <= 64 && c->blr_small && c->npad_small;
+  auto finish_terms = [&]() {   // the evidence of every head from the kernel's three sums (Bishop 3.82 / 3.86, as blr_fit_core)
+    if (!nll_out) return;
+    const double *t = reinterpret_cast<const double *>(static_cast<const char *>(c->pin_eval) + 16 * (size_t)S);
+    for (int s = 0; s < S; ++s) {
+      const double Em = 0.5 * bt[s] * t[3 * s + 2] - 0.5 * t[3 * s + 1];
+      nll_out[s] = -(0.5 * z * log(ap[s]) + 0.5 * N * log(bt[s]) - Em - t[3 * s] - 0.5 * N * log(2.0 * M_PI));
+    }
+  };
+  auto reports_clean = [&]() {
+    const int *rep = static_cast<const int *>(c->pin_eval);
+    for (int s = 0; s < S; ++s)
+      if (rep[4 * s] != 0 || rep[4 * s + 1] != 0) return false;
+    return true;
+  };
+  if (!exchange) {
+    B7_TRY(rc);
+    if (fast) {
+      B7_TRY(blr_marg_fast(c, net, X0, Y0, N, S, ap, bt, mn, z, spec, nll_out != nullptr));
+      B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true, true));
+      B7_TRY(exch_wait_mirror(c));
+      if (reports_clean()) {
+        finish_terms();
+        c->fitted = false;   // the context's own fit slot holds none of the S heads
+        return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
+      }
+      if (jitter_used) *jitter_used = -2.0;
+    }
+    B7_TRY(blr_marg_slow(c, net, X0, Y0, N, S, ap, bt, mn, z, spec, nll_out));
+    B7_TRY(exch_local(c, (double)S, global_row_offset, rank, world, true, true));
+    B7_TRY(exch_wait_mirror(c));
+    return exch_conclude(c, c->tab_host, world, best_val, best_idx1);
+  }
+  // with a communicator: the local part first (a rank that fails still reaches the collective with a failure record)
+  if (rc == B7_OK && c->M > 0) {
+    bool done = false;
+    if (fast) {
+      rc = blr_marg_fast(c, net, X0, Y0, N, S, ap, bt, mn, z, spec, nll_out != nullptr);
+      if (rc == B7_OK) rc = score_flush_pending(c);
+      if (rc == B7_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? B7_OK : b7_fail(c, B7_ERR_HIP, "blr_eval_nominate_marg: stream failed");
+      if (rc == B7_OK && reports_clean()) {
+        finish_terms();
+        done = true;
+      } else if (rc == B7_OK && jitter_used) {
+        *jitter_used = -2.0;
+      }
+    }
+    if (rc == B7_OK && !done) rc = blr_marg_slow(c, net, X0, Y0, N, S, ap, bt, mn, z, spec, nll_out);
+  }
+  if (rc == B7_OK) rc = exch_local(c, (double)S, global_row_offset, rank, world, true);
   const std::string own = c->err;
   if (rc != B7_OK) B7_TRY(exch_fail_record(c, rank, world, rc));
   B7_TRY(exch_allreduce(c));

@@ -297,6 +297,12 @@ int launch_potrf_small(b7_ctx *c, int B, const double *K, double *L, double *Lin
                        double extra, int *info, int *report_dev, int64_t sK, int64_t sL, int64_t sdinv, int64_t svec, int sinfo);
 int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, const double *yv, double alpha_prec, double beta,
                           int *report_dev);
+int launch_blr_heads_small(b7_ctx *c, int S, const double *Z, int N, int z, int ldz, const double *yraw_dev, const double *hyp3_dev,
+                           double *L, double *Linv, double *m, double *b, int *info, int *report_dev, double *terms);
+int launch_post_heads(b7_ctx *c, int S, const double *Linv, const double *feat, int64_t rows, int64_t Mtotal, double *var, int64_t svar,
+                      const double *zero_dev, const double *invbeta_dev);
+int launch_gemv_rows_batch(b7_ctx *c, int S, const double *A, int lda, const double *x, int64_t sx, int n, const double *base_dev,
+                           int64_t rows, double *y, int64_t sy);
 int launch_nll_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_host, double *terms_dev, int *info_dev,
                      unsigned *done_dev);
 // kpost_small.hip

@@ -22,14 +22,28 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr int ZLD = NB + 1;  // row stride of a 64-observation chunk of Z in LDS
 constexpr int BLR_SMALL_LDS_DOUBLES = 2 * NB * DLD + 32 * TLD + NB * ZLD + 4 * NB;
 
+// Batch mode (hyp3 != nullptr: b7_blr_eval_nominate_marg, the S (alpha, beta, mean) samples of a marginalised head): blockIdx.x =
+// sample; hyp3 = [S alpha | S beta | S mean] on the device, yv holds the RAW responses and beta (y - mean) is formed here (the
+// same rounded operations as the host forms for a single head); outputs are strided per sample (64 x 64 matrices, 64-vectors,
+// 4 ints) and terms[3 s ..] receives what the evidence needs: sum log L_kk, b'm, sum (y - mean)^2.
 __global__ void __launch_bounds__(256)
     blr_head_small_kernel(const double *__restrict__ Z, int N, int z, int ldz, const double *__restrict__ yv, double alpha_prec,
                           double beta, double *__restrict__ Lout, double *__restrict__ Linv, double *__restrict__ mvec,
-                          double *__restrict__ bout, int *__restrict__ info, int *__restrict__ report) {
+                          double *__restrict__ bout, int *__restrict__ info, int *__restrict__ report,
+                          const double *__restrict__ hyp3, int S, double *__restrict__ terms) {
   extern __shared__ __align__(16) double sm[];
   __shared__ int inf[4];
   double *A = sm, *X = A + NB * DLD, *T = X + NB * DLD, *Zc = T + 32 * TLD, *bv = Zc + NB * ZLD, *tv = bv + NB, *yc = tv + NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  double mean_s = 0.0;
+  if (hyp3) {
+    const int sidx = blockIdx.x;
+    alpha_prec = hyp3[sidx], beta = hyp3[S + sidx], mean_s = hyp3[2 * S + sidx];
+    Lout += (size_t)sidx * NB * NB, Linv += (size_t)sidx * NB * NB, mvec += (size_t)sidx * NB, bout += (size_t)sidx * NB;
+    info += 4 * sidx;
+    if (report) report += 4 * sidx;
+  }
+  double rr = 0.0;  // batch mode: sum (y - mean)^2 over this thread's share (threads 0..63, ascending chunks)
   if (tid < 4) inf[tid] = 0;
   // the wave's tiles of G (on and below the diagonal, dealt round-robin): q = wave, wave + 4, wave + 8 (< 10)
   d4_t acc[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
@@ -56,7 +70,15 @@ __global__ void __launch_bounds__(256)
       const int r = rq + 4 * i;
       Zc[r * ZLD + col] = (n0 + r < N && col < z) ? pv[i] : 0.0;
     }
-    if (tid < NB) yc[tid] = (n0 + tid < N) ? py : 0.0;
+    if (tid < NB) {
+      double yvn = py;
+      if (hyp3) {  // beta (y - mean), and the evidence's sum of squared residuals on the way
+        const double res = py - mean_s;
+        yvn = beta * res;
+        if (n0 + tid < N) rr = __builtin_fma(res, res, rr);
+      }
+      yc[tid] = (n0 + tid < N) ? yvn : 0.0;
+    }
     __syncthreads();
     if (n0 + NB < N) fetch(n0 + NB);
 #pragma unroll
@@ -127,6 +149,23 @@ __global__ void __launch_bounds__(256)
     Linv[e] = j <= i ? X[i * DLD + j] : 0.0;
   }
   __syncthreads();
+  if (terms && wave == 0) {  // the evidence's pieces (batch mode): sum_k log L_kk, b'm, sum (y - mean)^2, each a wave butterfly
+    double ld = lane < z ? log(A[lane * DLD + lane]) : 0.0;
+    double a2 = 0.0;
+    for (int i = lane; i < NB; ++i) a2 = __builtin_fma(X[i * DLD + lane], tv[i], a2);   // m_lane, as above
+    double qm = lane < z ? bv[lane] * a2 : 0.0;
+    double r2 = rr;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ld += __shfl_xor(ld, o);
+      qm += __shfl_xor(qm, o);
+      r2 += __shfl_xor(r2, o);
+    }
+    if (lane == 0) {
+      double *t3 = terms + 3 * (size_t)blockIdx.x;
+      t3[0] = ld, t3[1] = qm, t3[2] = r2;
+    }
+  }
   if (tid < 4) {
     info[tid] = inf[tid];
     if (report) report[tid] = inf[tid];
@@ -218,9 +257,28 @@ int launch_blr_head_small(b7_ctx *c, const double *Z, int N, int z, int ldz, con
     if (c->device < 64) attr_done[c->device] = true;
   }
   hipLaunchKernelGGL(blr_head_small_kernel, dim3(1), dim3(256), lds, c->stream, Z, N, z, ldz, yv, alpha_prec, beta, (double *)c->L.p,
-                     (double *)c->Linv.p, (double *)c->alpha.p, (double *)c->resid.p, (int *)c->info.p, report_dev);
+                     (double *)c->Linv.p, (double *)c->alpha.p, (double *)c->resid.p, (int *)c->info.p, report_dev,
+                     (const double *)nullptr, 1, (double *)nullptr);
   B7_HIP(c, hipGetLastError());
   c->linv_done = true;
+  return B7_OK;
+}
+
+// S heads over the same features (b7_blr_eval_nominate_marg): hyp3_dev = [S alpha | S beta | S mean], yraw_dev the raw responses;
+// L, Linv [S][64 x 64], m, b [S][64], info [S][4] (+ report in mapped host memory), terms [S][3] (sum log L_kk, b'm, sum r^2).
+int launch_blr_heads_small(b7_ctx *c, int S, const double *Z, int N, int z, int ldz, const double *yraw_dev, const double *hyp3_dev,
+                           double *L, double *Linv, double *m, double *b, int *info, int *report_dev, double *terms) {
+  PhaseScope ps(c, "potrf");
+  if (z < 1 || z > NB || c->Npad != NB) return b7_fail(c, B7_ERR_INVALID, "blr_heads_small: z %d, padded %d", z, c->Npad);
+  const size_t lds = sizeof(double) * BLR_SMALL_LDS_DOUBLES;
+  static bool attr_done[64] = {false};
+  if (c->device >= 64 || !attr_done[c->device]) {
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(blr_head_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->device < 64) attr_done[c->device] = true;
+  }
+  hipLaunchKernelGGL(blr_head_small_kernel, dim3(S), dim3(256), lds, c->stream, Z, N, z, ldz, yraw_dev, 0.0, 0.0, L, Linv, m, b, info,
+                     report_dev, hyp3_dev, S, terms);
+  B7_HIP(c, hipGetLastError());
   return B7_OK;
 }
 

@@ -487,6 +487,20 @@ __global__ void __launch_bounds__(256)
   if (lane == 0) y[row0 + row] = base + s;
 }
 
+// S heads over the same rows (blockIdx.y = s): y_s[row] = base[s] + sum_k A[row][k] x_s[k]; the same sums as gemv_rows_kernel
+__global__ void __launch_bounds__(256)
+    gemv_rows_batch_kernel(const double *__restrict__ A, int lda, const double *__restrict__ x, int64_t sx, int n,
+                           const double *__restrict__ base, int64_t Mtotal, double *__restrict__ y, int64_t sy) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, sidx = blockIdx.y;
+  if (row >= Mtotal) return;
+  x += sidx * sx;
+  double s = 0.0;
+  for (int k = lane; k < n; k += 64) s += A[row * lda + k] * x[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) y[sidx * sy + row] = base[sidx] + s;
+}
+
 // Zt[k][i] = Z[i][k] (Z: n x ldz row-major, Zt: zpad x nk, zero padded) -- the layout gemm_nt wants for Z'Z
 __global__ void transpose_pad_kernel(const double *__restrict__ Z, int n, int ldz, int z, double *__restrict__ Zt,
                                      int zpad, int nk) {
@@ -682,6 +696,16 @@ int launch_gemv_rows(b7_ctx *c, const double *A, int lda, const double *x, int n
   if (rows <= 0) return B7_OK;
   hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, A, lda, x, n, base,
                      row0, Mtotal, y);
+  B7_HIP(c, hipGetLastError());
+  return B7_OK;
+}
+
+int launch_gemv_rows_batch(b7_ctx *c, int S, const double *A, int lda, const double *x, int64_t sx, int n, const double *base_dev,
+                           int64_t rows, double *y, int64_t sy) {
+  PhaseScope ps(c, "mean");
+  if (rows <= 0) return B7_OK;
+  hipLaunchKernelGGL(gemv_rows_batch_kernel, dim3((unsigned)((rows + 3) / 4), S), dim3(256), 0, c->stream, A, lda, x, sx, n, base_dev,
+                     rows, y, sy);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
 }

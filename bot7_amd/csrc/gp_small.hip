@@ -633,7 +633,9 @@ int gs_launch(b7_ctx *c, const GsArgs &a, const double *hyp_host) {
 
 }  // namespace
 
-bool gp_small_applies(const b7_ctx *c) { return c->Npad <= 128 && c->dfit <= 32 && c->ycols == 1; }
+// (the kernel pads N to one or two 64-blocks itself; a context told to pad small sets to 128 -- the diagnostic build's
+// B7_NPAD_SMALL=0 -- keeps the general path)
+bool gp_small_applies(const b7_ctx *c) { return c->Npad == (c->N > 64 ? 128 : 64) && c->dfit <= 32 && c->ycols == 1; }
 
 // B likelihood evaluations of the resident data.  hyp_dev: [B x d lengthscales | B amp | B noise | B mean] (b7_gp_nll_batch's
 // pack, device-visible); terms_dev[2 B], info_dev[4 B]; done_dev (nullable): a word the kernel sets to 1 after its results

@@ -746,4 +746,18 @@ int launch_post_batch(b7_ctx *c, int S, const double *Linv, const double *ks, in
   a.pb.var_add = c->opts.var_with_noise ? noise_dev : nullptr;
   return dispatch_post(c, a, 0, rows, Mtotal);
 }
+
+// S Bayesian-linear heads over the SAME feature rows (b7_blr_eval_nominate_marg): Linv_s = Linv + s Npad^2, the features are
+// shared (stride 0), var_s = 1/beta_s + |Linv_s z|^2 with zero_dev[S] = 0 and invbeta_dev[S] on the device
+int launch_post_heads(b7_ctx *c, int S, const double *Linv, const double *feat, int64_t rows, int64_t Mtotal, double *var, int64_t svar,
+                      const double *zero_dev, const double *invbeta_dev) {
+  PhaseScope ps(c, "post");
+  PostArgs a{Linv, feat, var, 0.0, 1.0, 0.0, S, PostBatch{}};
+  a.pb.sLinv = (int64_t)c->Npad * c->Npad;
+  a.pb.sks = 0;
+  a.pb.svar = svar;
+  a.pb.base = zero_dev;
+  a.pb.var_add = invbeta_dev;
+  return dispatch_post(c, a, 0, rows, Mtotal);
+}
 #endif

@@ -7,9 +7,12 @@ the network up to the basis layer (:155-171), then the Bayesian-linear predictiv
 out of scope): the trained layers come in through ``config['network']`` =
 {'weights': [...], 'biases': [...], 'activation': 'Tanh'|'ReLU'|'Sigmoid'|None}.
 
-The head (gp.models.bayes_linear, absent `gp` package) is standard Bayesian linear regression with prior
-precision ``config['alpha']`` and noise precision ``config['beta']``; hyp='marginalize' (:109) is the host's job:
-pass a list of (alpha, beta) pairs as ``hyp`` and predict_device averages nothing -- the scores accumulate."""
+The head (gp.models.bayes_linear, absent `gp` package: PARITY UNPINNED) is standard Bayesian linear regression with prior
+precision ``config['alpha']`` and noise precision ``config['beta']``.  ``predict`` / ``predict_device`` take ONE point
+``hyp = {'alpha', 'beta', 'mean'}``.  The reference's default hyp='marginalize' (:109, passed to the predictor at :174) is realised
+as the analogue of bayesopt:eval's GP loop by ``eval_nominate`` below: a LIST of hyp tables (drawn by the host, e.g. with
+bot7.samplers.slice over ``nll``) -> S heads over the same features, the acquisition of every head added in sample order,
+score:div(S), score:max(1) -- one library call, b7_blr_eval_nominate_marg."""
 import numpy as np
 
 from .abstract import abstract
@@ -76,6 +79,22 @@ class dngo(abstract):
             self.ctx.grid_upload(np.atleast_2d(np.asarray(X_hid, dtype=np.float64)))
         self.ctx.blr_basis(self.weights, self.biases, self.activation)   # :164-171 for X1, on the device
         self.ctx.blr_predict(download=False)
+
+    def eval_nominate(self, X_obs, Y_obs, X_hid, hyps, score="ei", fmin=None, tradeoff=None, upper=False, sign=-1.0, want_nll=False):
+        """The marginalised nomination (models/dngo.lua:109 'marginalize'): hyps = [{'alpha', 'beta', 'mean'}, ...]; returns
+        (value, 1-based index[, nll per sample]).  One hyp table = b7_blr_eval_nominate's single head."""
+        if isinstance(hyps, dict):
+            hyps = [hyps]
+        if not self._is_resident(X_hid):
+            self.ctx.grid_upload(np.atleast_2d(np.asarray(X_hid, dtype=np.float64)))
+        out = self.ctx.blr_eval_nominate_marg(self.weights, self.biases, self.activation, np.atleast_2d(np.asarray(X_obs, dtype=np.float64)),
+                                              Y_obs, [h["alpha"] for h in hyps], [h["beta"] for h in hyps], [h["mean"] for h in hyps],
+                                              score=score, fmin=fmin, tradeoff=tradeoff, upper=upper, sign=sign, want_nll=want_nll)
+        return (out[0], out[1], out[3]) if want_nll else (out[0], out[1])
+
+    def nll(self, X_obs, Y_obs, hyp=None):
+        """Negative log evidence of the head under hyp (what a host-side sampler of (alpha, beta) walks)."""
+        return self.fit(X_obs, Y_obs, hyp, want_nll=True)["nll"]
 
     def predict(self, X_obs, Y_obs, X_hid, hyp=None, req=None):
         """dngo:predict (:108-175) -> {'mean': M x 1, 'var': M}."""

@@ -342,7 +342,8 @@ int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec
 
 /* bayesopt:eval's DNGO branch + nominate as ONE call (bots/bayesopt.lua:65-66, :96 over models/dngo.lua:155-175):
  * b7_blr_fit_x(net, X0, Y0, ...) + b7_blr_basis(net, resident grid) + b7_blr_predict + the acquisition of `spec` (written,
- * not accumulated: this branch has no hyper marginalisation) + b7_score_finish_global, enqueued back to back with ONE host
+ * not accumulated: ONE point (alpha_prec, beta, mean); b7_blr_eval_nominate_marg below marginalises over S of them) +
+ * b7_score_finish_global, enqueued back to back with ONE host
  * synchronisation; the candidates' features are recomputed on every call, as the reference does.  Results as the separate
  * calls (the posterior mean comes out of the feature kernel itself: its last bits may differ from b7_blr_predict's).
  * best_idx1 / global_row_offset / communicator as b7_eval_nominate.  jitter_used (nullable): 0, or < 0 when the head's
@@ -350,6 +351,19 @@ int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec
 int b7_blr_eval_nominate(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec,
                          double beta, double mean, const b7_score_spec *spec, int64_t global_row_offset, double *best_val,
                          int64_t *best_idx1, double *jitter_used);
+
+/* The same with the head's hypers MARGINALISED -- models/dngo.lua:109 defaults hyp to 'marginalize' and hands it to the predictor
+ * (:174).  gp.models.bayes_linear's own treatment lives in the absent `gp` package (parity unpinned); what is built is the
+ * analogue of bayesopt:eval's GP loop (bots/bayesopt.lua:69-79): S samples (alpha_prec[s], beta[s], mean[s]) -- drawn by the host,
+ * e.g. with bot7.samplers.slice over the evidence nll_out returns --, S heads fitted over the SAME features (one basis pass over
+ * the observations, one over the candidates; for z <= 64 features the S heads are S workgroups of one launch), the acquisition
+ * of every head added in sample order, score:div(S), score:max(1).  nll_out (nullable, S entries): the negative log evidence of
+ * every head, as b7_blr_fit's.  jitter_used (nullable): 0, or < 0 when a head's Cholesky needed utils.math.chol's jitter schedule
+ * and the nomination was redone head by head through b7_blr_fit_x.  S = 1 is b7_blr_eval_nominate. */
+int b7_blr_eval_nominate_marg(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, int S,
+                              const double *alpha_prec, const double *beta, const double *mean, const b7_score_spec *spec,
+                              int64_t global_row_offset, double *best_val, int64_t *best_idx1, double *nll_out,
+                              double *jitter_used);
 
 /* ---- one process, several GPUs: the reference's single-process trial loop over a sharded grid ----------------- *
  * The reference is ONE LuaJIT process (bots/abstract.lua:155-169); a group lets that one process drive n GPUs, so the

@@ -69,6 +69,7 @@ int b7_exchange_info(b7_ctx *ctx, int *world, int64_t *rows_per_rank, int64_t *w
 typedef struct { int kind; double tradeoff; int upper; double sign; const double *fmin; } b7_score_spec;
 int b7_eval_nominate(b7_ctx *ctx, int S, const b7_hyp *hyps, const b7_score_spec *spec, int64_t global_row_offset, double *best_val, int64_t *best_idx1, double *jitter_out, int *info_out);
 int b7_blr_eval_nominate(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, double alpha_prec, double beta, double mean, const b7_score_spec *spec, int64_t global_row_offset, double *best_val, int64_t *best_idx1, double *jitter_used);
+int b7_blr_eval_nominate_marg(b7_ctx *ctx, const b7_mlp *net, const double *X0, const double *Y0, int N, int S, const double *alpha_prec, const double *beta, const double *mean, const b7_score_spec *spec, int64_t global_row_offset, double *best_val, int64_t *best_idx1, double *nll_out, double *jitter_used);
 typedef struct b7_group b7_group;
 int b7_group_create(b7_group **out, int n, const int *device_ids);
 void b7_group_destroy(b7_group *g);

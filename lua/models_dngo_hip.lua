@@ -57,4 +57,23 @@ function dngo:predict(X0, Y0, X1, hyp, req, skip)
   return {mean = mean, var = var}
 end
 
+-- hyp = 'marginalize' (models/dngo.lua:109, handed to the predictor at :174) as ONE library call, b7_blr_eval_nominate_marg: `hyps`
+-- is a list of {alpha=, beta=, mean=} tables (drawn by the host, e.g. bot7.samplers.slice over the evidence); S heads over the
+-- same features, the acquisition of every head added in sample order, score:div(S), score:max(1).  spec: a b7_score_spec
+-- (scores_hip.lua builds it).  Returns the 1-based index of the nominee in X1 (the resident grid) and its score.
+function dngo:eval_nominate(X0, Y0, X1, hyps, spec)
+  self.network:evaluate()
+  local net, keep = pack_network(self)
+  local S = #hyps
+  local a, b, m = ffi.new('double[?]', S), ffi.new('double[?]', S), ffi.new('double[?]', S)
+  for s = 1, S do a[s-1] = hyps[s].alpha; b[s-1] = hyps[s].beta; m[s-1] = hyps[s].mean end
+  assert(hip.group == nil, 'bot7hip: the DNGO head runs on one GPU (no group)')
+  if not hip.is_resident(X1) then hip.upload_grid(X1) end
+  local X0c, Y0c = hip.pin(X0), hip.pin(Y0)
+  local val, idx, jit = ffi.new('double[1]'), ffi.new('int64_t[1]'), ffi.new('double[1]')
+  hip.check(hip.C.b7_blr_eval_nominate_marg(hip.ctx, net, hip.data(X0c), hip.data(Y0c), X0:size(1), S, a, b, m, spec, 0, val, idx,
+                                            nil, jit))
+  return tonumber(idx[0]), val[0]
+end
+
 return dngo

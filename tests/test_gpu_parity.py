@@ -990,15 +990,24 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(ctx):
     # the same two ranks through bench.py's PRODUCT path (--backend rccl: b7_comm_init + b7_eval_nominate's exchange branch),
     # with RCCL's transport served by the shared-memory test double of tests/stub (RCCL refuses two ranks on one device)
     sys.path.insert(0, os.path.join(root, "tests"))
-    from test_sharded_loop import _stub_lib
+    from test_sharded_loop import _diag_lib, _stub_lib
     three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                             "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(root, "bench.py"),
                             "--gpus", "2", "--candidates", "65536"] + common,
-                           capture_output=True, text=True, env=dict(env, B7_RCCL_LIB=_stub_lib()), timeout=300)
+                           capture_output=True, text=True, env=dict(env, B7_RCCL_LIB=_stub_lib(), BOT7HIP_LIB=_diag_lib()), timeout=300)   # the override lives in the diagnostic build
     assert three.returncode == 0, three.stderr[-2000:]
     b3 = json.loads(three.stdout.strip().splitlines()[-1])
     assert b3["n_gpus"] == 2 and "b7_eval_nominate" in b3["step_api"] and "ncclAllReduce" in b3["config"]["parallelism"]
     assert b3["best"] == b1["best"], "winner through the communicator path differs from the unsharded arg-max"
+    # `python bench.py --gpus 2` with NO launcher: the single-process group (b7_group_*), here with both members on cuda:0 --
+    # records merged on the host, then the grouped ncclAllReduce forced through the in-process test double
+    for extra_env, rccl_ranks in (({}, 0), ({"B7_RCCL_LIB": _stub_lib(), "B7_GROUP_EXCHANGE": "rccl"}, 2)):
+        four = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--virtual-ranks", "--candidates", "65536"]
+                              + common, capture_output=True, text=True, env=dict(env, **extra_env), timeout=300)
+        assert four.returncode == 0, four.stderr[-2000:]
+        b4 = json.loads(four.stdout.strip().splitlines()[-1])
+        assert b4["n_gpus"] == 2 and b4["config"]["layout"] == "group" and b4["config"]["rccl_ranks"] == rccl_ranks
+        assert b4["best"] == b1["best"], "the group's winner differs from the unsharded arg-max"
 
 
 # ---- edge cases through the C ABI ---------------------------------------------------------------------------------
@@ -2099,3 +2108,137 @@ def test_completion_word_and_stream_wait_give_the_same_answers(ctx, orc):
         c.score_reset()
         got.append(r)
     assert got[0] == got[1]
+
+
+# ---- round 4: the reference's own regime (N <= 128, d <= 32) in three launches -------------------------------------------
+def _diag_context(monkeypatch, **env):
+    """A context of the DIAGNOSTIC build (tools/_build/libbot7hip_diag.so) under the given switches (read at b7_create)."""
+    import bot7_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    try:
+        return bot7_amd.Context(0, lib="diag")
+    finally:
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("N,d", [(2, 2), (5, 1), (16, 3), (25, 2), (48, 6), (63, 6), (64, 6), (65, 6), (80, 6), (81, 5), (96, 6), (100, 6),
+                                 (112, 6), (113, 9), (127, 16), (128, 32), (100, 32), (33, 31)])
+def test_small_problem_kernels_equal_the_general_schedule_bit_for_bit(ctx, orc, monkeypatch, N, d):
+    """gp_small_kernel (the whole fit, or the likelihood, of a hyper vector in one eight-wave workgroup), kpost_small_kernel
+    (K(X*,X) + mean + variance, K* never stored) and score_finish_slot_kernel (score:add x S + div + arg-max + record) against the
+    general schedule -- observation scaling, ksx_kernel, persistent Cholesky, trmv launches, post_kernel, ei_batch / finish /
+    argmax_slot -- selected in the diagnostic build by B7_FIT_SMALL=0 B7_KPOST_SMALL=0 B7_NLL_SMALL=2 (round 3's four-wave
+    likelihood kernel): L, L^-1, alpha, the likelihoods, posterior mean and variance, the marginalised scores and the nominations
+    must agree BIT FOR BIT, across one / two 64-blocks, partly and wholly padded 16-strips, every width class."""
+    ref = _diag_context(monkeypatch, B7_FIT_SMALL="0", B7_NLL_SMALL="2", B7_KPOST_SMALL="0")
+    try:
+        rng = np.random.default_rng(1000 * N + d)
+        X = rng.random((N, d))
+        Y = np.sin(X.sum(1, keepdims=True) * 3.0) + 0.01 * rng.normal(size=(N, 1))
+        ls = np.full(d, d / 8.0) * (0.5 + rng.random(d))
+        hyps = [{"lenscale_sq": ls * (1 + 0.05 * s), "amp": 1.3, "noise": 1e-3, "mean": 0.1} for s in range(10)]
+        outs = []
+        for c in (ctx, ref):
+            o = c.gp_fit(X, Y, ls, 1.3, 1e-3, 0.1, want_nll=True)
+            L, al, Li = c.gp_download(N)
+            c.gp_set_data(X, Y)
+            nll5 = c.gp_nll_batch(np.outer(0.5 + 0.1 * np.arange(5), ls), 1.3, 1e-3, 0.1)
+            nll1 = c.gp_nll_batch(ls, 1.3, 1e-3, 0.1)
+            c.grid_sobol(3000 + N, d, 5, download=False)
+            p = c.gp_predict_hyp(ls, 1.3, 1e-3, 0.1, download=True)
+            b1 = c.eval_nominate(hyps[:1], score="ei", fmin=[float(Y.min())])
+            s1 = c.score_finish(1.0, download=True)[2]
+            b10 = c.eval_nominate(hyps, score="ei", fmin=[float(Y.min())])
+            s10 = c.score_finish(1.0, download=True)[2]
+            b3 = c.eval_nominate(hyps[:3], score="cb")
+            s3 = c.score_finish(1.0, download=True)[2]
+            outs.append({"L": L, "alpha": al, "Linv": Li, "fit_nll": np.asarray(o["nll"]), "nll5": nll5, "nll1": nll1, "mean": p["mean"],
+                         "var": p["var"], "b1": np.array(b1), "s1": s1, "b10": np.array(b10), "s10": s10, "b3": np.array(b3), "s3": s3})
+        for k in outs[0]:
+            assert outs[0][k].tobytes() == outs[1][k].tobytes(), "N %d d %d: %s differs from the general schedule" % (N, d, k)
+        # and against the oracle (parity unpinned: no reference fixture for the GP algebra)
+        f = orc.gp.fit(X, Y, ls, 1.3, 1e-3, 0.1)
+        assert relerr(outs[0]["fit_nll"], f.nll, floor=1e-9) < 1e-9
+        mu_o, var_o = orc.gp.predict(f, orc.c.sobol(3000 + N, d, 5))
+        assert relerr(outs[0]["mean"], mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(outs[0]["var"], var_o) < REL
+    finally:
+        ref.close()
+
+
+def test_small_fit_kernel_hands_a_failed_pivot_to_the_jitter_schedule(ctx, orc):
+    """Duplicated observations and no noise: gp_small_kernel reports the pivot, b7_gp_fit assembles K through the general front
+    end and runs utils/math.lua:159-218's retries; b7_eval_nominate redoes the nomination per sample.  Jitter, first failing
+    pivot and the posterior follow the oracle's schedule (N = 40 + 7 and N = 90 + 7: one and two blocks)."""
+    for n0 in (40, 90):
+        X_obs, Y, X_hid, hyp = make_problem(ctx, orc, 6, n0, 700, B.hartmann6)
+        Xd, Yd = np.concatenate([X_obs, X_obs[:7]]), np.concatenate([Y, Y[:7]])
+        h = dict(hyp, noise=0.0)
+        out = ctx.gp_fit(Xd, Yd, want_nll=True, **h)
+        f = orc.gp.fit(Xd, Yd, **h)
+        assert out["jitter"] == f.jitter and out["jitter"] > 0 and out["info"] == f.info
+        ctx.grid_upload(X_hid)
+        mu, var = ctx.gp_predict()
+        mu_o, var_o = orc.gp.predict(f, X_hid)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < 1e-4      # cond(K + eps I) ~ 1e8 here
+        ctx.gp_set_data(Xd, Yd)
+        v, i, rep = ctx.eval_nominate([h, dict(h, amp=h["amp"] * 1.1)], score="cb", want_report=True)
+        assert (rep["jitter"] > 0).all() and (rep["info"] > 0).all()
+        acc = np.zeros(X_hid.shape[0])
+        for hh in (h, dict(h, amp=h["amp"] * 1.1)):
+            m_o, v_o = orc.gp.predict(orc.gp.fit(Xd, Yd, **hh), X_hid)
+            orc.c.accumulate(acc, orc.c.cb(m_o, v_o))
+        orc.c.divide(acc, 2.0)
+        top2 = np.partition(acc, -2)[-2:]
+        if top2[1] - top2[0] > 1e-6 * abs(top2[1]):
+            assert i == orc.c.argmax_first(acc)[0]
+
+
+@pytest.mark.parametrize("S", [1, 4, 10])
+def test_dngo_head_marginalised_over_hyper_samples(ctx, orc, S):
+    """models/dngo.lua:109,174 (hyp = 'marginalize') as b7_blr_eval_nominate_marg at BASELINE config 5's full shape (3 x 50 tanh
+    basis, N = 256, 65536 candidates): S samples (alpha, beta, mean), S heads over the same features, score:add per sample,
+    score:div(S), score:max(1) -- against the oracle's loop (oracle/blr.py per sample, cport.accumulate / divide / argmax_first) over
+    the WHOLE grid: the winner, its value, the marginalised scores left in the accumulator, the evidence of every head; S = 1
+    must be b7_blr_eval_nominate.  A 70-feature head (two 64-blocks) takes the head-by-head path and must agree as well.
+    PARITY UNPINNED: gp.models.bayes_linear's own marginalisation lives in the absent `gp` package."""
+    from oracle import blr
+    import bench
+    d, N, M = 5, 256, 65536
+    X_obs = bench.make_inputs(ctx, d, N, M, 0, M)
+    X_hid = ctx.grid_download()
+    rng = np.random.default_rng(0)
+    for width in ((50, 50, 50), (50, 70)):
+        dims = [d] + list(width)
+        W = [rng.normal(scale=1.0 / np.sqrt(dims[i]), size=(dims[i + 1], dims[i])) for i in range(len(width))]
+        b = [rng.normal(scale=0.1, size=dims[i + 1]) for i in range(len(width))]
+        Z0 = blr.basis(X_obs, W, b, "Tanh")
+        Y = Z0 @ rng.normal(size=(width[-1], 1)) + 0.1 * rng.normal(size=(N, 1))
+        al = 0.5 + rng.random(S) * 2.0
+        be = 50.0 + rng.random(S) * 100.0
+        mn = float(np.mean(Y)) + 0.05 * rng.normal(size=S)
+        Z1 = blr.basis(X_hid, W, b, "Tanh")
+        for kind in ("ei", "cb"):
+            acc = np.zeros(M)
+            nll_o = []
+            for s_ in range(S):
+                f = blr.fit(Z0, Y, al[s_], be[s_], mn[s_])
+                nll_o.append(float(f["nll"]))
+                m_o, v_o = blr.predict(f, Z1)
+                orc.c.accumulate(acc, orc.c.ei(m_o, v_o, [float(Y.min())]) if kind == "ei" else orc.c.cb(m_o, v_o))
+            orc.c.divide(acc, float(S))
+            wi, wv = orc.c.argmax_first(acc)
+            v, i, jit, nll = ctx.blr_eval_nominate_marg(W, b, "Tanh", X_obs, Y, al, be, mn, score=kind, fmin=[float(Y.min())],
+                                                        want_nll=True)
+            _, _, got = ctx.score_finish(1.0, download=True)
+            assert jit == 0.0
+            assert np.max(np.abs(got - acc)) < 1e-8 * max(1.0, np.abs(acc).max())
+            top2 = np.partition(acc, -2)[-2:]
+            if top2[1] - top2[0] > 1e-7 * max(1.0, abs(top2[1])):
+                assert i == wi
+            assert v == pytest.approx(wv, rel=1e-6, abs=1e-9)
+            assert np.allclose(nll, nll_o, rtol=1e-9, atol=1e-7)
+            if S == 1:
+                v1, i1 = ctx.blr_eval_nominate(W, b, "Tanh", X_obs, Y, al[0], be[0], mn[0], score=kind, fmin=[float(Y.min())])
+                assert (i1, v1) == (i, pytest.approx(v, rel=1e-12))

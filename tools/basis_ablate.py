@@ -25,7 +25,7 @@ def build():
                 obj = os.path.join(ROOT, "tools", "_build", "extras_mlp%d.o" % v)
                 subprocess.check_call([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DB7_MLP_ABLATE=%d" % v, "-c", os.path.join(B.CSRC, src), "-o", obj])
             objs.append(obj)
-        subprocess.check_call([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib(v)] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+        subprocess.check_call([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib(v)] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
         print("built", lib(v), flush=True)
 
 

@@ -28,7 +28,7 @@ def build():
             subprocess.check_call([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DB7_GS_STAMP", "-c", os.path.join(B.CSRC, src), "-o", obj])
         objs.append(obj)
     subprocess.check_call([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
-                          ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                          ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
     print("built", LIB)
 
 

@@ -29,7 +29,7 @@ def build():
                 subprocess.check_call([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + [define, "-DB7_DIAG", "-c", os.path.join(B.CSRC, src), "-o", obj])
             objs.append(obj)
         subprocess.check_call([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs +
-                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                              ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
         print("built", lib)
 
 

@@ -28,7 +28,7 @@ def build():
             subprocess.check_call([B.HIPCC] + B.FLAGS + ["-DB7_POST_STAMPS", "-c", os.path.join(B.CSRC, src), "-o", obj])
         objs.append(obj)
     subprocess.check_call([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs +
-                          ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+                          ["-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-Wl,-Bsymbolic"])
     print("built", OUT)
 
 
