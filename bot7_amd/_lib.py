@@ -415,6 +415,21 @@ class Context(object):
         self._ck(self._L.b7_gp_nll_batch(self._h, B, _ptr(ls), _ptr(a), _ptr(nz), _ptr(m), _ptr(nll), _ptr(jit), _ptr(info)))
         return (nll, jit, info) if want_info else nll
 
+    def gp_nll1(self, lenscale_sq, amp, noise, mean):
+        """One likelihood evaluation (B = 1) through preallocated argument buffers: what a slice-sampler step costs, without the
+        per-call array conversions of gp_nll_batch (the C call itself is ~20-35 us; those conversions were another ~15).
+        Returns (nll, jitter, info)."""
+        d = getattr(self, "_data_d", -1)
+        buf = getattr(self, "_nll1_buf", None)
+        if buf is None or buf[0].size != d:
+            arr = [np.empty(d), np.empty(1), np.empty(1), np.empty(1), np.empty(1), np.empty(1), np.empty(1, dtype=np.int32)]
+            buf = self._nll1_buf = arr + [[_ptr(a) for a in arr]]
+        buf[0][:] = lenscale_sq
+        buf[1][0], buf[2][0], buf[3][0] = amp, noise, mean
+        p = buf[7]
+        self._ck(self._L.b7_gp_nll_batch(self._h, 1, p[0], p[1], p[2], p[3], p[4], p[5], p[6]))
+        return float(buf[4][0]), float(buf[5][0]), int(buf[6][0])
+
     def chol(self, src):
         """utils.math.chol(src, 'L') with the jitter schedule; returns (L, jitter_used, info_first)."""
         A = _f64(src)

@@ -283,23 +283,47 @@ static int grid_copy_out(b7_ctx *c, double *out_host) {
 
 // grids/sobol.lua:82-85, grids/random.lua:29-32: only one of mins / maxes given.  The shift / scale uses the column minima /
 // maxima of the WHOLE grid: with a communicator the shards' extremes are combined by one all-reduce (min / max of d doubles).
-static int onesided(b7_ctx *c, const double *mins, const double *maxes) {
-  const int d = c->d;
-  std::vector<double> ext(2 * (size_t)d);
-  for (int k = 0; k < d; ++k) ext[k] = INFINITY, ext[d + k] = -INFINITY;  // an empty shard constrains nothing
-  if (c->M > 0) B7_TRY(b7_grid_colrange(c, ext.data(), ext.data() + d));
-  double *use = mins ? ext.data() : ext.data() + d;
-  if (c->comm && c->comm_world > 1) {
-    for (int k0 = 0; k0 < d; k0 += 128)
-      B7_TRY(b7_comm_allreduce_f64(c, use + k0, std::min(128, d - k0), mins ? B7_COMM_MIN : B7_COMM_MAX));
+// That makes the call COLLECTIVE, so a rank that failed before it (rc_before: a bad argument, an allocation) still enters it:
+// the reduced vector carries one more element, a status that the failing rank sets to the value that wins the reduction
+// (-inf under MIN, +inf under MAX), and every rank returns an error together instead of the others waiting for ever.
+static int onesided(b7_ctx *c, const double *mins, const double *maxes, int rc_before) {
+  const bool collective = c->comm && c->comm_world > 1;
+  if (rc_before != B7_OK && !collective) return rc_before;
+  const int d = (rc_before == B7_OK) ? c->d : 0;
+  std::vector<double> ext(2 * (size_t)B7_MAX_D + 2);
+  double *lo = ext.data(), *hi = ext.data() + B7_MAX_D + 1;
+  for (int k = 0; k <= B7_MAX_D; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;  // an empty shard constrains nothing
+  int rc = rc_before;
+  const std::string own = c->err;
+  if (rc == B7_OK && c->M > 0) {
+    std::vector<double> cmin(d), cmax(d);
+    rc = b7_grid_colrange(c, cmin.data(), cmax.data());
+    if (rc == B7_OK) {
+      memcpy(lo, cmin.data(), sizeof(double) * d);
+      memcpy(hi, cmax.data(), sizeof(double) * d);
+    }
   }
+  const std::string own2 = rc != B7_OK ? c->err : own;
+  double *use = mins ? lo : hi;
+  if (collective) {
+    // every rank reduces the same B7_MAX_D + 1 values whatever its own d (a failed rank may not know it): the extremes, then
+    // the status
+    use[B7_MAX_D] = rc == B7_OK ? (mins ? INFINITY : -INFINITY) : (mins ? -INFINITY : INFINITY);
+    const int rcc = b7_comm_allreduce_f64(c, use, B7_MAX_D + 1, mins ? B7_COMM_MIN : B7_COMM_MAX);
+    if (rc != B7_OK) {
+      c->err = own2;
+      return rc;
+    }
+    if (rcc != B7_OK) return rcc;
+    if (use[B7_MAX_D] == (mins ? -INFINITY : INFINITY))
+      return b7_fail(c, B7_ERR_COMM, "one-sided grid map: another rank failed before the exchange of the column extremes; no rank maps its shard");
+  }
+  if (rc != B7_OK) return rc;
   if (c->M == 0) return B7_OK;
   return b7_grid_apply_onesided(c, mins, maxes, use);
 }
 
-int b7_grid_sobol(b7_ctx *c, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
-                  double *out_host) {
-  if (!c) return B7_ERR_INVALID;
+static int grid_sobol_local(b7_ctx *c, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes) {
   if (size < 0 || skip < 0) return b7_fail(c, B7_ERR_INVALID, "sobol: size %lld skip %lld", (long long)size, (long long)skip);
   if (dims < 1 || dims >= 40)  // assert(C.dims and C.dims < C.max_dims), grids/sobol.lua:36
     return b7_fail(c, B7_ERR_RANGE, "sobol: dims %d not in [1, 39] (grids/sobol.lua:36)", dims);
@@ -309,19 +333,32 @@ int b7_grid_sobol(b7_ctx *c, int64_t size, int dims, int64_t skip, const double 
                    (long long)(size + skip - 1));
   const bool both = mins && maxes;
   B7_TRY(grid_alloc(c, size, dims));
-  B7_TRY(launch_sobol(c, cur_grid(c), size, dims, skip, both ? mins : nullptr, both ? maxes : nullptr));
-  if (!both && (mins || maxes)) B7_TRY(onesided(c, mins, maxes));
+  return launch_sobol(c, cur_grid(c), size, dims, skip, both ? mins : nullptr, both ? maxes : nullptr);
+}
+
+int b7_grid_sobol(b7_ctx *c, int64_t size, int dims, int64_t skip, const double *mins, const double *maxes,
+                  double *out_host) {
+  if (!c) return B7_ERR_INVALID;
+  int rc = grid_sobol_local(c, size, dims, skip, mins, maxes);
+  if ((mins != nullptr) != (maxes != nullptr)) rc = onesided(c, mins, maxes, rc);  // collective with a communicator: entered on failure too
+  B7_TRY(rc);
   return grid_copy_out(c, out_host);
+}
+
+static int grid_random_local(b7_ctx *c, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins,
+                             const double *maxes) {
+  if (size < 0 || row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "random grid: size/offset negative");
+  const bool both = mins && maxes;
+  B7_TRY(grid_alloc(c, size, dims));
+  return launch_random_grid(c, cur_grid(c), size, dims, seed, row_offset, both ? mins : nullptr, both ? maxes : nullptr);
 }
 
 int b7_grid_random(b7_ctx *c, int64_t size, int dims, uint64_t seed, int64_t row_offset, const double *mins,
                    const double *maxes, double *out_host) {
   if (!c) return B7_ERR_INVALID;
-  if (size < 0 || row_offset < 0) return b7_fail(c, B7_ERR_INVALID, "random grid: size/offset negative");
-  const bool both = mins && maxes;
-  B7_TRY(grid_alloc(c, size, dims));
-  B7_TRY(launch_random_grid(c, cur_grid(c), size, dims, seed, row_offset, both ? mins : nullptr, both ? maxes : nullptr));
-  if (!both && (mins || maxes)) B7_TRY(onesided(c, mins, maxes));
+  int rc = grid_random_local(c, size, dims, seed, row_offset, mins, maxes);
+  if ((mins != nullptr) != (maxes != nullptr)) rc = onesided(c, mins, maxes, rc);
+  B7_TRY(rc);
   return grid_copy_out(c, out_host);
 }
 
@@ -372,9 +409,8 @@ int b7_torch_rand(uint64_t seed, int64_t n, int resolution, double *out) {
   return B7_OK;
 }
 
-int b7_grid_random_torch(b7_ctx *c, int64_t size, int dims, uint64_t seed, int resolution, const double *mins,
-                         const double *maxes, double *out_host) {
-  if (!c) return B7_ERR_INVALID;
+static int grid_random_torch_local(b7_ctx *c, int64_t size, int dims, uint64_t seed, int resolution, const double *mins,
+                                   const double *maxes) {
   if (size < 0 || (resolution != 32 && resolution != 53))
     return b7_fail(c, B7_ERR_INVALID, "random grid (torch stream): size >= 0, resolution 32 or 53");
   std::vector<double> u((size_t)size * (dims > 0 ? dims : 0));
@@ -390,9 +426,16 @@ int b7_grid_random_torch(b7_ctx *c, int64_t size, int dims, uint64_t seed, int r
       B7_HIP(c, hipMemcpyAsync(v_dev, stage, sizeof(double) * dims, hipMemcpyHostToDevice, c->stream));
       B7_TRY(launch_col_affine(c, cur_grid(c), c->M, dims, v_dev, pass == 0));
     }
-  } else if (mins || maxes) {
-    B7_TRY(onesided(c, mins, maxes));
   }
+  return B7_OK;
+}
+
+int b7_grid_random_torch(b7_ctx *c, int64_t size, int dims, uint64_t seed, int resolution, const double *mins,
+                         const double *maxes, double *out_host) {
+  if (!c) return B7_ERR_INVALID;
+  int rc = grid_random_torch_local(c, size, dims, seed, resolution, mins, maxes);
+  if ((mins != nullptr) != (maxes != nullptr)) rc = onesided(c, mins, maxes, rc);  // collective with a communicator: entered on failure too
+  B7_TRY(rc);
   return grid_copy_out(c, out_host);
 }
 

@@ -420,7 +420,12 @@ int launch_score_finish_slot(b7_ctx *c, const b7_ctx::PendingScore &ps, double *
                              int rank, int world, int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec,
                              unsigned *host_done) {
   PhaseScope scope(c, "score");
-  const int nb = nblocks(c, M);
+  // small grids (fewer 256-thread blocks than CUs: 2e4 candidates are 79): one wave per block, so that the S acquisitions per
+  // candidate -- ~2000 dependent fp64 instructions a thread at S = 10 -- run on every CU instead of a third of them
+  const int threads = (M + 255) / 256 < c->cus ? 64 : 256;
+  int64_t nbl = (M + threads - 1) / threads;
+  if (nbl > (int64_t)c->cus * 8) nbl = (int64_t)c->cus * 8;
+  const int nb = (int)(nbl < 1 ? 1 : nbl);
   B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
   Best *part = (Best *)c->part.p;
   if (!c->ticket.p) {  // the ticket counter: a word of its own (c->part is shared scratch), zero between launches
@@ -430,7 +435,7 @@ int launch_score_finish_slot(b7_ctx *c, const b7_ctx::PendingScore &ps, double *
   unsigned *ticket = (unsigned *)c->ticket.p;
   ScoreArgs sa{ps.mu, ps.var, ps.S, ps.kind, (long long)ps.stride, ps.fd, c->fmin_scalar, ps.tradeoff, ps.sign, ps.upper,
                acc_mode(c, acc, true) == 2 ? 1 : 0};
-  hipLaunchKernelGGL(score_finish_slot_kernel, dim3(nb), dim3(256), 0, c->stream, sa, acc, (long long)M, divisor, part, ticket,
+  hipLaunchKernelGGL(score_finish_slot_kernel, dim3(nb), dim3(threads), 0, c->stream, sa, acc, (long long)M, divisor, part, ticket,
                      (unsigned long long *)tab_dev, rank, world, (long long)offset, grid, d, all_slots ? 1 : 0,
                      (unsigned long long *)host_rec, host_done);
   B7_HIP(c, hipGetLastError());

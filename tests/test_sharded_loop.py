@@ -453,6 +453,37 @@ def test_processes_sharing_the_gpu_run_the_trial_loop_through_the_communicator_p
 
 # ---- the boundary from plain C -----------------------------------------------------------------------------------------------
 @pytest.mark.gpu
+def test_one_sided_grid_map_is_a_collective_every_rank_leaves(orc, tmp_path):
+    """grids/sobol.lua:82-83 (mins only) on a grid sharded over ranks with a communicator: the column minima of the WHOLE grid are
+    combined by one all-reduce, so the call is collective -- and a rank that fails BEFORE it (here: 40 dims, refused as
+    grids/sobol.lua:36 refuses them) must still enter it with a failure status, so that every rank returns (its own error /
+    B7_ERR_COMM) instead of the others waiting in ncclAllReduce for ever.  Two processes on cuda:0 over the
+    shared-memory RCCL double."""
+    import json
+    import subprocess
+    world = 2
+    env = dict(os.environ, B7_RCCL_LIB=_stub_lib(), BOT7HIP_LIB=_diag_lib(), PYTHONPATH=ROOT)
+    ident = ("b7one_%d" % os.getpid()).encode().hex()
+    outs = [str(tmp_path / ("r%d.json" % r)) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_onesided_worker.py"), str(r), str(world), ident, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+    res = [json.load(open(o)) for o in outs]
+    mins = np.array([-1.0, 0.5, 2.0, 0.0, 1e-3])
+    want = orc.c.sobol(1001, 5, 3, mins=mins)
+    assert np.array_equal(np.concatenate([np.array(r["rows"]) for r in res]), want)
+    assert res[1]["failure"][0] == -6, res[1]["failure"]          # its own B7_ERR_RANGE
+    assert res[0]["failure"][0] == -7, res[0]["failure"]          # B7_ERR_COMM: another rank failed
+
+
+@pytest.mark.gpu
 def test_grouped_rccl_branch_runs_with_virtual_ranks(tmp_path):
     """csrc/group.hip's grouped-RCCL branch (ncclCommInitAll, ncclGroupStart / one all-reduce per member / ncclGroupEnd, the
     table read from member 0, the redo with rewritten records) with n = 2, 3, 8 members on ONE GPU: B7_GROUP_EXCHANGE=rccl
