@@ -420,12 +420,10 @@ int launch_score_finish_slot(b7_ctx *c, const b7_ctx::PendingScore &ps, double *
                              int rank, int world, int64_t offset, const double *grid, int d, bool all_slots, uint64_t *host_rec,
                              unsigned *host_done) {
   PhaseScope scope(c, "score");
-  // small grids (fewer 256-thread blocks than CUs: 2e4 candidates are 79): one wave per block, so that the S acquisitions per
-  // candidate -- ~2000 dependent fp64 instructions a thread at S = 10 -- run on every CU instead of a third of them
-  const int threads = (M + 255) / 256 < c->cus ? 64 : 256;
-  int64_t nbl = (M + threads - 1) / threads;
-  if (nbl > (int64_t)c->cus * 8) nbl = (int64_t)c->cus * 8;
-  const int nb = (int)(nbl < 1 ? 1 : nbl);
+  // (one-wave blocks for small grids -- 313 instead of 79 workgroups for 2e4 candidates -- measured SLOWER: 145 vs 139 us per
+  // nomination at N = 100, S = 10; the last block's pass over four times as many partials costs more than the spread saves)
+  const int threads = 256;
+  const int nb = nblocks(c, M);
   B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
   Best *part = (Best *)c->part.p;
   if (!c->ticket.p) {  // the ticket counter: a word of its own (c->part is shared scratch), zero between launches
