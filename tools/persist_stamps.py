@@ -29,7 +29,7 @@ for _ in range(3):
         c.gp_nll_batch(hyp[0][None, :], hyp[1], hyp[2], hyp[3])
     else:
         c.gp_fit(X, Y, *hyp)
-L = _lib.load()
+L = c._L
 buf = np.zeros(1 << 16, dtype=np.uint64)
 nb, nj = C.c_int(), C.c_int()
 rc = L.b7dbg_persist_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(nb), C.byref(nj))
