@@ -49,6 +49,7 @@ WORKLOADS = {
     "default": (6, 100, 20000, "hartmann6", "ei"),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; measured 74.5-77.3 (profiles/r01_mfma_f64_probe.txt)
+GPU_CLOCK_HZ = 2.4e9           # shader clock under load (profiles/r04_post_clock.txt)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
 SOBOL_SKIP = 2                 # config.skip of the pool: see "Inputs" above
 PMC_SUMMARIES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01z_pmc_summary.json")  # newest first
@@ -261,6 +262,11 @@ def run_default(args):
     nll_t = kern[n_last]["nll_kernel_us"] * 1e-6
     post_us = kern[n_last]["nominate_phase_us"].get("kpost") or kern[n_last]["nominate_phase_us"].get("post")
     post_flops = 10.0 * M * nn * nn
+    nt = -(-len(Xo) // 16)
+    chain_us = nt * 3925 / GPU_CLOCK_HZ * 1e6
+    dpad = 4 if d <= 4 else 8 if d <= 8 else 16 if d <= 16 else 32
+    strip_cycles = 64.0 * (nt * max(1, dpad // 4) + 2 * nt * (nt + 1)) + 64 * nt * 4.8
+    pipe_us = 10 * -(-M // 16) * strip_cycles / (1024 * GPU_CLOCK_HZ) * 1e6
     line = {
         "metric": "BO trials/sec at the reference's default regime (hartmann6 d=6, 2e4 Sobol candidates, nSamples=10, budget %d)" % budget,
         "value": args.steps * budget / elapsed, "unit": "trials/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -275,17 +281,27 @@ def run_default(args):
                    "parallelism": "one GPU, one context (the regime is latency-bound)", "device": info["name"]},
         "ms_per_trial": split,
         "kernels_by_N": kern,
-        "roofline": {"bound": "mfma", "kernel": "nll_small_kernel (one density evaluation of the slice sampler: K + Cholesky + solve in one "
-                                                "workgroup; ~%d launches per trial)" % round(split.get("nll_calls", 0) / max(1, split.get("model_based_trials", 1))),
+        "roofline": {"bound": "dependent chain",
+                     "kernel": "gp_small_kernel<0> (one density evaluation of the slice sampler: K + Cholesky + solve in one "
+                               "workgroup; ~%d launches per trial)" % round(split.get("nll_calls", 0) / max(1, split.get("model_based_trials", 1))),
+                     "floor_us": chain_us, "frac_of_floor": chain_us * 1e-6 / nll_t if nll_t > 0 else None,
                      "achieved": nll_flops / nll_t / 1e12 if nll_t > 0 else None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": nll_flops / nll_t / 1e12 / FP64_MFMA_PEAK_TFLOPS if nll_t > 0 else None, "traffic": None,
                      "flops_per_launch": nll_flops, "avg_launch_ms": nll_t * 1e3,
-                     "note": "a dependent chain on one CU (two 64-column factor-and-invert routines of ~8.7 us each, VALU-issue bound): "
-                             "latency-bound, so the throughput fraction is tiny by construction; DESIGN.md section 8 (round 4) has its critical path"},
-        "roofline_nominate": {"bound": "mfma", "kernel": "posterior variance of the S = 10 fits over the grid at N = %s" % n_last,
+                     "note": "one workgroup on one CU; floor_us = the ceil(N/16) pivot chains of the two 64-column factor routines alone "
+                             "(3 925 cycles per 16 columns: sixteen dependent {rsqrt, scale, rank-1} steps on one wave; stamps in "
+                             "profiles/r04_gp_small_stamps.txt); frac against the MFMA peak is tiny by construction and kept only "
+                             "because the contract asks for it"},
+        "roofline_nominate": {"bound": "fp64 pipe (MFMA+VALU)",
+                              "kernel": "kpost_small_kernel (K*, mean and variance of the S = 10 fits over the grid at N = %s, K* never stored)" % n_last,
                               "achieved": post_flops / (post_us * 1e-6) / 1e12 if post_us else None, "peak": FP64_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": post_flops / (post_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS if post_us else None,
-                              "traffic": None, "flops_per_launch": post_flops, "avg_launch_ms": post_us * 1e-3 if post_us else None},
+                              "pipe_us": pipe_us, "frac_of_pipe": pipe_us / post_us if post_us else None,
+                              "traffic": None, "flops_per_launch": post_flops, "avg_launch_ms": post_us * 1e-3 if post_us else None,
+                              "note": "pipe_us = what the one fp64 pipe per SIMD needs for the kernel's instructions: per 16-candidate "
+                                      "strip NT dpad/4 + 2 NT (NT + 1) MFMAs of 64 cycles (NT = ceil(N/16): distances, then the lower "
+                                      "triangle of L^-1 against the K* tile) and 64 NT exponential instructions of 4.8 cycles, over "
+                                      "1 024 SIMDs at 2.4 GHz; avg_launch_ms is the library's phase timer (events around the launch)"},
         "best": g["best"], "nominees_first_10": g["nominees"][:10],
     }
     if not args.no_cpu_baseline:
@@ -650,14 +666,24 @@ def main():
             # Cholesky + explicit inverse of the factor: N^3/3 flop each (the trailing updates alone: N^3/3)
             chol_flops = 2.0 * float(N) ** 3 / 3.0
             t_s = potrf["ms_avg"] * 1e-3
-            roofline_fit = {"bound": "mfma", "kernel": "potrf_persist_kernel (blocked Cholesky + inverse of the factor, one persistent launch)",
+            # what bounds ONE factorisation is not the pipe but the chain of things that wait for each other: per 64-column panel
+            # the four 16-column pivot chains of the factor routine (3 925 cycles each: 16 x {rsqrt, scale, rank-1} on one wave),
+            # its four in-block updates (720), the next block row's solve (1.55 us) and the update of the next diagonal block
+            # (0.80 us) -- stamps read inside the launch, profiles/r04_persist_stamps_N2048.txt; DESIGN section 8, "The
+            # factorisation's floor".  Publishing / storing the inverse, the grid-wide flag and the tail of the inverse's doubling
+            # are the schedule's own overhead and are NOT in the floor.
+            panels = Npad // 64
+            floor_ms = panels * ((4 * 3925 + 4 * 720) / GPU_CLOCK_HZ * 1e3 + 1.55e-3 + 0.80e-3)
+            roofline_fit = {"bound": "dependent chain", "kernel": "potrf_persist_kernel (blocked Cholesky + inverse of the factor, one persistent launch)",
+                            "floor_ms": floor_ms, "frac_of_floor": floor_ms / potrf["ms_avg"], "panels": panels,
                             "achieved": chol_flops / t_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": chol_flops / t_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                             "flops_per_launch": chol_flops, "avg_launch_ms": potrf["ms_avg"],
                             "trailing_update_frac": 0.5 * chol_flops / t_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                            "note": "one fit is a 32-panel dependent chain on one CU with the rest of the chip pulling tile jobs; "
-                                    "MFMA-busy and utilisation of the side-by-side shapes (ten fits, sixteen likelihoods: 38 %) "
-                                    "in profiles/r03_potrf_pmc.json"}
+                            "note": "one fit is a chain of Npad/64 panels on one CU with the rest of the chip pulling tile jobs: floor_ms is "
+                                    "that chain at the measured cost of its links, frac / peak (the fp64-MFMA pipe) are kept for "
+                                    "reference only; MFMA-busy and utilisation of the side-by-side shapes (ten fits, sixteen "
+                                    "likelihoods: 38 %) in profiles/r03_potrf_pmc.json"}
         if ksx:
             ksx_bytes = rows_per_launch * (8.0 * Npad + 8.0 * d)
             # what actually bounds the kernel: the ONE fp64 pipe per SIMD that MFMA and VALU instructions share.  Per 64 outputs a

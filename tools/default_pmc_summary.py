@@ -15,11 +15,14 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         rows += list(csv.DictReader(fh))
 per = {}
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     k = per.setdefault(name, {"disp": {}, "ctr": {}})
     k["disp"][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     k["ctr"].setdefault(r["Counter_Name"], {})[r["Dispatch_Id"]] = float(r["Counter_Value"])
-out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python3 tools/nominate_default_trace.py "
+out = {"note": "GRBM_GUI_ACTIVE also counts the dispatch's front and back end, which is not small against kernels of tens of "
+               "microseconds: effective_clock_GHz comes out above the real 2.4 and mfma_busy is UNDER-stated by the same factor; "
+               "kpost_small_kernel's launches are half S = 1 and half S = 10 nominations",
+       "command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python3 tools/nominate_default_trace.py "
                   "(B7_TRACE_CASE=1: N = 100, d = 6, 20000 candidates, S = 1 and S = 10 nominations)", "kernels": {}}
 for name, k in sorted(per.items(), key=lambda kv: -sum(kv[1]["disp"].values())):
     n = len(k["disp"])

@@ -46,7 +46,7 @@ def run():
         L.b7dbg_gs_stamps(buf)
         for wv, who in ((0, "wave 0"), (1, "wave 4")):
             st = [buf[32 * wv + i] for i in range(14)]
-            print("  %s (%s): total %d cycles = %.1f us at 2.4 GHz... (s_memtime runs at 100 MHz x ratio; cycles as reported)" % (title, who, st[13] - st[0], (st[13] - st[0]) / 100.0))
+            print("  %s (%s): total %d cycles (s_memtime: shader clock; %.1f us at 2.4 GHz)" % (title, who, st[13] - st[0], (st[13] - st[0]) / 2400.0))
             print("     (diagnostic: the wave's K sub-tile a second time, code already fetched: %d cycles; SIMD of waves 0..7: %s)"
                   % (buf[32 * wv + 15] - buf[32 * wv + 14], [int(buf[16 + k]) for k in range(8)]))
             prev = st[0]
