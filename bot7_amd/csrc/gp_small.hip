@@ -10,10 +10,14 @@
 //             the persistent factorisation and three triangular matrix-vector launches of the general schedule in one).
 //
 // Structure.  512 threads.  Waves 0..3 are the four waves b7diag::diag_core is written for; waves 4..7 keep in step with its
-// barriers (diag_bystander) and do what nothing on the dependent chain waits for: the K sub-tiles of block row 1 while
-// block (0,0) is factored, those of block (1,1) while L21 is solved and squared, the stores to global memory.  Four 64 x 66
-// images in LDS change roles as the data die:  B0 observations -> inv(L22);  B1 K11 / L11 -> K22 / L22;  B2 K21 -> L21 ->
-// L21 inv(L11) -> inv(L)21;  B3 inv(L11).
+// barriers (diag_bystander).  While wave 0 runs block (0,0)'s four pivot chains, everybody who is idle -- waves 4..7, and waves
+// 1..3 through the routine's hook -- assembles what does not depend on L11: the rest of K11, all of K21, the K entries of
+// block (1,1) (kept in LDS until L21 L21' is there to be subtracted); while it runs block (1,1)'s, waves 4..7 do the
+// likelihood's first solve and the update of the second residual.  Four 64 x 66 images in LDS change roles as the data die:
+// B0 observations -> inv(L22);  B1 K11 / L11 -> K22 / L22;  B2 K21 -> L21 -> L21 inv(L11) -> inv(L)21;  B3 inv(L11).
+// The kernel is latency all the way: ONE workgroup executes ~40 KB of straight-line code once, out of an instruction cache that
+// is cold at every launch (a sub-tile's code costs 2 300 cycles the first time and 1 700 the second) -- hence one instance per
+// block count (TWO) and one site of sub-tile code per caller (k_job) rather than one per use.
 //
 // Bits.  K entries: the chain of v_mfma_f64_16x16x4 over the input dimensions, the (c - xs/2) - zs/2 argument and the table
 // exponential of ksx_kernel (ksx_exp.h).  L, L^-1: diag_core per 64-block; L21 = C inv(L11)' with the blocks above inv(L11)'s
@@ -48,7 +52,9 @@ constexpr int OLD = 33;         // row stride of the observation image [128][OLD
 constexpr int BUF = NB * DLD;   // one 64 x 66 image
 static_assert(128 * OLD <= BUF, "the observation image lives in one block image");
 constexpr int GS_THREADS = 512;
-constexpr int GS_LDS_DOUBLES = 4 * BUF + 32 * TLD + 5 * 128 + 32 + 128 + 64;
+constexpr int K22_STASH = 6;  // sub-tiles of block (1,1) whose K entries are formed ahead of time (all there is up to N = 112)
+constexpr int GS_LDS_DOUBLES = 4 * BUF + 32 * TLD + 5 * 128 + 32 + 128 + 64 + K22_STASH * 256;
+static_assert(GS_LDS_DOUBLES * 8 + 512 <= 160 * 1024, "LDS budget (the static arrays -- inf, the diagnostic build's stamps -- need < 512 B)");
 
 struct GsInline {  // the hypers of a single evaluation, passed in the kernel arguments (no second trip over the bus)
   double v[35];
@@ -196,15 +202,19 @@ __device__ __forceinline__ void store_zero_block(double *__restrict__ dst, int64
   for (int e = t0; e < NB * NB; e += nt) dst[(int64_t)(e >> 6) * ld + (e & 63)] = 0.0;
 }
 
-template <int MODE>
+// TWO: N > 64 (two 64-blocks).  A template parameter, not a run-time test: the kernel runs every instruction once, out of a cold
+// instruction cache, and each block of code it has to jump over is a fetch from memory (a one-block evaluation that carried
+// the two-block phases as untaken branches was 0.9 us slower).
+template <int MODE, bool TWO>
 __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline hin) {
   extern __shared__ __align__(16) double sm[];
   __shared__ int inf[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15,
             lq = lane >> 4;
   const int N = a.N, d = a.d, B = a.B;
-  const int npad = N > 64 ? 128 : 64;
-  const bool two = npad == 128, aux = wave >= 4;
+  constexpr int npad = TWO ? 128 : 64;
+  constexpr bool two = TWO;
+  const bool aux = wave >= 4;
   double *B0 = sm, *B1 = B0 + BUF, *B2 = B1 + BUF, *B3 = B2 + BUF, *T = B3 + BUF;
   double *r = T + 32 * TLD;   // [128] residual y - mean
   double *hn = r + 128;       // [128] half norms
@@ -214,6 +224,7 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   double *w = tv + 128;       // [32]
   double *tab = w + 32;       // [128] amp 2^(j/128)
   double *red = tab + 128;    // [64]
+  double *ks22 = red + 64;    // [K22_STASH][4][64] K entries of block (1,1)'s first sub-tiles, accumulator layout
   double *obs = B0;
   const double *hyp = a.use_inline ? hin.v : a.hyp_mem;
   const double *ls = hyp + (size_t)b * d;
@@ -236,7 +247,9 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       v[t] = idx < total ? a.xobs[idx] : 0.0;
     }
     for (int e = tid; e < 128 * OLD; e += GS_THREADS) obs[e] = 0.0;
-    lds_barrier();
+    zero_block(B3);       // the inverse's image and the identity corner of block (0,0) (rows 0..15 x columns 48..63: sub-tile
+    identity_corner(B1);  // (0,3), which no K sub-tile writes): nothing touches them before the factor routine -- done here,
+    lds_barrier();        // while the loads are in flight
     GS_STAMP(1);
     const float rd = 1.0f / (float)d;
 #pragma unroll
@@ -253,9 +266,13 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   lds_barrier();
   if (tid < 128) {
     double s = 0.0;
-    for (int k = 0; k < a.dpad; ++k) {  // the columns beyond dpad add (0 * 0) * 0
-      const double x = obs[tid * OLD + k];
-      s += (x * x) * w[k];  // Z_ss = (Z.^2) * inv_ls, :79
+    for (int k = 0; k < a.dpad; k += 4) {  // the columns beyond dpad add (0 * 0) * 0; dpad is a multiple of 4: four reads in flight
+      const double x0 = obs[tid * OLD + k], x1 = obs[tid * OLD + k + 1], x2 = obs[tid * OLD + k + 2], x3 = obs[tid * OLD + k + 3];
+      const double w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+      s += (x0 * x0) * w0;  // Z_ss = (Z.^2) * inv_ls, :79
+      s += (x1 * x1) * w1;
+      s += (x2 * x2) * w2;
+      s += (x3 * x3) * w3;
     }
     hn[tid] = 0.5 * s;
   }
@@ -290,7 +307,6 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
     k_tile_vals(obs, wq, hn, tab, 0, 0, N, noise, R1_I[wave], R1_J[wave], ks, kv);
     tile_put(B1, R1_I[wave], R1_J[wave], kv);
   }
-  zero_block(B3);
   GS_STAMP(3);
 #ifdef B7_GS_STAMP
   {  // the same sub-tile once more: what does a K sub-tile cost when its code is already in the instruction cache?
@@ -303,32 +319,64 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
     if (blockIdx.x == 0 && lane == 0) b7_gs_stamps[16 + wave] = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);  // HW_ID.SIMD_ID
   }
 #endif
-  identity_corner(B1);  // rows 0..15 x columns 48..63: sub-tile (0,3), which no K sub-tile writes
   lds_barrier();
   GS_STAMP(4);
-  // ---- block (0,0): factor and invert on waves 0..3; waves 4..7 assemble what is left of K11 and all of K21 -> B2 meanwhile,
-  // one sub-tile per wave in front of each of the routine's four long phases (the 16-column factor steps) and of its tail
+  // ---- block (0,0): factor and invert on waves 0..3.  Everything else that can be known before L11 is assembled meanwhile, a
+  // sub-tile at a time, by whoever is idle: waves 4..7 during each of the routine's four 16-column pivot chains (3 900 cycles
+  // of wave 0's; a sub-tile is 1 700 - 2 300), waves 1..3 in the routine's hook -- they have nothing of their own in step 0
+  // and a few hundred cycles of it in steps 1..3.  What: K11's (3,2), (3,3) (first touched in step 1), the sixteen sub-tiles of
+  // K21 -> B2, and the K entries of the first six sub-tiles of block (1,1) -- all that is live up to N = 112 -- which wait in
+  // LDS (ks22) for the products they are held against further down.  Nothing is left for the routine's tail.
+  //   slot table (t = sub-tile (t >> 2, t & 3) of K21; q = lower sub-tile q of block (1,1)):
+  //     chain 0: waves 4..7: K11 (3,2), K11 (3,3), t0, t1     wave 1: t2    wave 2: q0    wave 3: q1
+  //     chain 1: waves 4..7: t3 .. t6                         waves 1..3: t7, t8, t9
+  //     chain 2: waves 4..7: t10 .. t13                       wave 3: t14   wave 1: t15
+  //     chain 3: waves 4..7: q2 .. q5
+  // ONE site of sub-tile code per caller (the kernel runs out of a cold instruction cache: every further copy is fetched from
+  // memory again).  job 0..15: K21's sub-tile t -> B2; 16..21: the K entries of block (1,1)'s sub-tile q = job - 16 -> ks22;
+  // 22, 23: K11's (3,2), (3,3) -> B1; < 0: nothing
+  auto k_job = [&](int job) {
+    if (job < 0) return;
+    int I0 = 64, J0 = 0, it = job >> 2, jt = job & 3;
+    if (job >= 22) {
+      I0 = 0, it = 3, jt = job - 20;
+    } else if (job >= 16) {
+      J0 = 64;
+      lower_tile(job - 16, it, jt);
+    }
+    double kv[4];
+    k_tile_vals(obs, wq, hn, tab, I0, J0, N, noise, it, jt, ks, kv);
+    if (job >= 16 && job < 22) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) ks22[(job - 16) * 256 + rr * 64 + lane] = kv[rr];
+    } else {
+      tile_put(job >= 22 ? B1 : B2, it, jt, kv);
+    }
+  };
+  auto core_hook = [&](int kb, int wv) {  // waves 1..3, after their own share of step kb's factor phase (kb = 4: the tail)
+    if (!two) return;
+    int job = -1;
+    if (kb == 0) job = wv == 1 ? 2 : 14 + wv;       // t2, q0, q1
+    else if (kb == 1) job = 6 + wv;                  // t7, t8, t9
+    else if (kb == 2 && wv != 2) job = wv == 3 ? 14 : 15;
+    k_job(job);
+  };
   if (!aux) {
 #ifdef B7_GS_STAMP
     __shared__ unsigned long long dst_[24];  // the factor routine's own phase stamps (slots 2..17), block 0
-    diag_core<1, true, NoHook, true>(B1, B3, T, 0, inf, dst_, NoHook(), N < NB ? N : NB);
+    diag_core<1, true, decltype(core_hook), true>(B1, B3, T, 0, inf, dst_, core_hook, N < NB ? N : NB);
     if (blockIdx.x == 0 && tid < 24) b7_gs_stamps[32 + 8 + tid] = dst_[tid];
 #else
-    diag_core<1, false, NoHook, true>(B1, B3, T, 0, inf, nullptr, NoHook(), N < NB ? N : NB);  // B1 -> L11 (lower), B3 = inv(L11)
+    diag_core<1, false, decltype(core_hook), true>(B1, B3, T, 0, inf, nullptr, core_hook, N < NB ? N : NB);  // B1 -> L11 (lower), B3 = inv(L11)
 #endif
   } else {
     diag_bystander<true>([&](int bi) {
-      if (bi & 1) return;
-      const int g = wave - 4, slot = 4 * (bi >> 1) + g;  // slots 0, 1: K11's (3,2), (3,3); slots 2..17: K21's sixteen
-      double kv[4];
-      if (slot < 2) {
-        k_tile_vals(obs, wq, hn, tab, 0, 0, N, noise, 3, 2 + slot, ks, kv);
-        tile_put(B1, 3, 2 + slot, kv);
-      } else if (two && slot < 18) {
-        const int q = slot - 2;
-        k_tile_vals(obs, wq, hn, tab, 64, 0, N, noise, q >> 2, q & 3, ks, kv);
-        tile_put(B2, q >> 2, q & 3, kv);
-      }
+      if ((bi & 1) || bi > 6) return;  // the even phases 0, 2, 4, 6 are wave 0's pivot chains
+      const int g = wave - 4;
+      int job;
+      if (bi == 0) job = g < 2 ? 22 + g : (two ? g - 2 : -1);
+      else job = !two ? -1 : bi == 2 ? 3 + g : bi == 4 ? 10 + g : 18 + g;
+      k_job(job);
     });
   }
   GS_STAMP(5);
@@ -336,9 +384,9 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   double *Lb = MODE == 1 && a.L ? a.L + (size_t)b * npad * npad : nullptr;
   double *Lib = MODE == 1 ? a.Linv + (size_t)b * npad * npad : nullptr;
   double *dib = MODE == 1 && a.dinv ? a.dinv + (size_t)b * npad * NB : nullptr;
-  if (aux == two) {  // two blocks: the helper waves (the others have the longer share of L21 below); one block: waves 0..3
-    const int t4 = tid & 255, row = t4 >> 2, part = t4 & 3;
-    if (MODE == 0) {  // z1 = inv(L11) r1: four lanes per row, ascending columns within each quarter, then the quarters in order
+  if (!two && !aux) {  // one block: z1 = inv(L11) r1 on waves 0..3 -- four lanes per row, ascending columns within each quarter,
+    const int row = tid >> 2, part = tid & 3;  // then the quarters in order; two blocks: below, off the path to block (1,1)
+    if (MODE == 0) {
       double acc = 0.0;
       for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(B3[row * DLD + k], r[k], acc);
       acc += __shfl_xor(acc, 1);
@@ -347,6 +395,7 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
     }
     if (part == 0) dg[row] = B1[row * DLD + row];
   }
+  if (two && wave == 1) dg[lane] = B1[lane * DLD + lane];  // before L11's image is given up (the barrier below)
   if (Lb) {
     store_block(B1, Lb, npad, true, tid, GS_THREADS);
     if (two) store_zero_block(Lb + NB, npad, tid, GS_THREADS);
@@ -372,17 +421,6 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
     GS_STAMP(7);
     // K22 - L21 L21' -> B1, lower sub-tiles only, a sub-tile per wave (two for waves 0, 1): its K entries (registers), the
     // 64-deep chain of L21 L21' from zero, then the subtraction
-    if (MODE == 0 && wave < 2) {  // r2 -= L21 z1: waves 0, 1 (their sub-tiles come last in the deal below), 32 rows a pass
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = 32 * pass + (tid >> 2), part = tid & 3;
-        double acc = 0.0;
-        for (int k = 16 * part; k < 16 * part + 16; ++k) acc = __builtin_fma(B2[row * DLD + k], z[k], acc);
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        if (part == 0) r[64 + row] = r[64 + row] - acc;
-      }
-    }
     // sub-tile q goes to wave (q + 2) mod 8: the first six -- all there is to compute up to N = 112 -- land on waves 2..7
     for (int q = (wave + 6) & 7; q < 10; q += 8) {
       int it, jt;
@@ -397,7 +435,12 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       const double *ar = B2 + (16 * it + lr) * DLD + lq, *br = B2 + (16 * jt + lr) * DLD + lq;
 #pragma unroll
       for (int k4 = 0; k4 < 16; ++k4) av[k4] = ar[4 * k4], bv[k4] = br[4 * k4];
-      k_tile_vals(obs, wq, hn, tab, 64, 64, N, noise, it, jt, ks, kv);
+      if (q >= K22_STASH) {
+        k_tile_vals(obs, wq, hn, tab, 64, 64, N, noise, it, jt, ks, kv);  // row strip 3 (N > 112): formed here
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) kv[rr] = ks22[q * 256 + rr * 64 + lane];
+      }
       d4_t u = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int k4 = 0; k4 < 16; ++k4) u = mfma_f64(av[k4], bv[k4], u);
@@ -441,7 +484,24 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       diag_core<1, false, NoHook, true>(B1, B0, T, 1, inf, nullptr, NoHook(), N - NB);  // B1 -> L22, B0 = inv(L22)
 #endif
     } else {
-      diag_bystander<true>([&](int) {});
+      // the helper waves have nothing to assemble any more.  MODE 0: what the second block's factor does not need happens
+      // here, off everybody's way -- z1 = inv(L11) r1 (four lanes per row, ascending columns within each quarter, then the
+      // quarters in order: the general path's sums) under the first pivot chain, r2 -= L21 z1 under the second; inv(L11)'s and
+      // L21's images stay as they are until the end of a likelihood evaluation.
+      diag_bystander<true>([&](int bi) {
+        if (MODE != 0 || (bi != 0 && bi != 2)) return;
+        const int row = (tid & 255) >> 2, part = tid & 3;
+        const double *m = (bi == 0 ? B3 : B2) + row * DLD + 16 * part, *v = (bi == 0 ? r : z) + 16 * part;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = __builtin_fma(m[k], v[k], acc);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) {
+          if (bi == 0) z[row] = acc;
+          else r[64 + row] = r[64 + row] - acc;
+        }
+      });
     }
     GS_STAMP(11);
     if (!aux) {
@@ -612,23 +672,27 @@ int ensure_gs_table(b7_ctx *c) {
   return B7_OK;
 }
 
-template <int MODE>
-int gs_launch(b7_ctx *c, const GsArgs &a, const double *hyp_host) {
+template <int MODE, bool TWO>
+int gs_launch2(b7_ctx *c, const GsArgs &a, const double *hyp_host) {
   B7_TRY(ensure_gs_table(c));
   const size_t lds = sizeof(double) * GS_LDS_DOUBLES;
   // the opt-in to > 64 KiB of dynamic LDS is per device: once per process AND device (a process may hold contexts on several)
   static bool attr_done[64] = {false};
   if (c->device >= 64 || !attr_done[c->device]) {
-    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gp_small_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(gp_small_kernel<MODE, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (c->device < 64) attr_done[c->device] = true;
   }
   GsInline hin = {};
   GsArgs k = a;
   k.use_inline = (a.B == 1 && hyp_host != nullptr) ? 1 : 0;
   for (int i = 0; k.use_inline && i < a.d + 3; ++i) hin.v[i] = hyp_host[i];
-  hipLaunchKernelGGL(gp_small_kernel<MODE>, dim3(a.B), dim3(GS_THREADS), lds, c->stream, k, hin);
+  hipLaunchKernelGGL((gp_small_kernel<MODE, TWO>), dim3(a.B), dim3(GS_THREADS), lds, c->stream, k, hin);
   B7_HIP(c, hipGetLastError());
   return B7_OK;
+}
+template <int MODE>
+int gs_launch(b7_ctx *c, const GsArgs &a, const double *hyp_host) {
+  return a.N > NB ? gs_launch2<MODE, true>(c, a, hyp_host) : gs_launch2<MODE, false>(c, a, hyp_host);
 }
 
 }  // namespace

@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "_build", "libbot7hip_gsstamp.so")
 NAMES = ["start", "hypers + loads landed, image zeroed", "image scattered, half norms, (fit: scaled observations out)", "K11 tiles",
-         "inverse image zeroed, corner", "diag_core 1 (helpers: K21)", "z1 / L11 out, L21 chains", "L21 image",
-         "update chains, r2 / L21 inv(L11) (helpers: K22, stores)", "barrier", "subtraction, images for block 2", "diag_core 2",
+         "(the diagnostic second sub-tile), barrier", "diag_core 1 (idle waves: K11 rest, K21, K22 entries)", "L11 out, L21 chains", "L21 image",
+         "L21 L21' chains and subtraction / L21 inv(L11), stores", "barrier", "images for block 2", "diag_core 2 (helpers: z1, r2)",
          "z2 / inverse's off-diagonal block, stores", "reductions / alpha"]
 
 
