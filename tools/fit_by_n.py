@@ -1,3 +1,5 @@
+"""The GP fit by N (2048 ... 8192, d = 32): wall time, the factorisation phase (Cholesky + inverse, one persistent launch up to
+N = 4096, panel launches above) and what fraction of the fp64-MFMA peak its 2N^3/3 flop make.  usage (GPU box): python tools/fit_by_n.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,3 +1,5 @@
+// Probe: issue rate of v_mfma_i32_16x16x64_i8 on gfx950 (what an int8 / Ozaki-split variance product would have to beat the fp64 MFMA
+// by; diagnostic tool, not product; the idea was dropped: VERDICT r3).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef int v4i __attribute__((ext_vector_type(4)));

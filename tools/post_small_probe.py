@@ -1,3 +1,5 @@
+"""Per-launch time of the K* assembly and of the posterior kernel at a one-block problem (N = 25, d = 2, 2e5 candidates): A/B of two
+builds through BOT7HIP_LIB.  usage (GPU box): [BOT7HIP_LIB=...] python tools/post_small_probe.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
