@@ -51,8 +51,14 @@ __host__ __device__ constexpr int kp_lds_doubles(int nt) {
   return tri(nt) * 256 + nt * (DPAD / 4) * 64 + 32 * nt + DPAD + 128;
 }
 
+// two workgroups per CU (four waves per SIMD: <= 128 registers) for the narrow classes up to seven row strips -- where two LDS
+// copies of a fit fit as well --: twice the waves to hide the exponential's dependent chain behind, and 16-candidate strips
+// dealt in units half the size
+__host__ __device__ constexpr int kp_waves_per_simd(int dpad, int nt) { return (dpad <= 8 && nt <= 7) ? 4 : 2; }
+
 template <int DPAD, int NT>
-__global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
+__global__ void __launch_bounds__(KP_THREADS) __attribute__((amdgpu_waves_per_eu(kp_waves_per_simd(DPAD, NT), 4)))
+kpost_small_kernel(KpArgs a) {
   constexpr int KS = DPAD / 4;
   extern __shared__ __align__(16) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
@@ -89,7 +95,9 @@ __global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
   // read-only, every wave runs by itself.
   const int64_t nstrips = (a.M + 15) >> 4;
   const int64_t W = (int64_t)gridDim.x * (KP_THREADS / 64);
-  for (int64_t st = (int64_t)blockIdx.x * (KP_THREADS / 64) + wave; st < nstrips; st += W) {
+  // (wave-major numbering: the waves that get one strip more than the others -- the remainder of nstrips / W -- are wave 0 of
+  // as many workgroups, not all eight waves of a few: no SIMD gets more than one extra strip)
+  for (int64_t st = (int64_t)wave * gridDim.x + blockIdx.x; st < nstrips; st += W) {
     // the candidates' B fragments (x[cand = l & 15][4 k4 + (l >> 4)], zero padded) and half norm xs/2 (ksx_kernel: one
     // ascending sum per candidate; every lane computes its candidate's, the four lane groups redundantly)
     double xf[KS], hq;
@@ -115,9 +123,15 @@ __global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
       d4_t c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int k4 = 0; k4 < KS; ++k4) c = mfma_f64(ZF[(J * KS + k4) * 64 + lane], xf[k4], c);
+      // (alpha's four entries: read ahead of the exponentials up to six row strips, behind them from seven on, where the
+      // registers they would hold across the chain are what keeps the instance at 128 and two workgroups on a CU)
       double hk[4], alj[4], arg[4], kv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hk[r] = zs[16 * J + lq + 4 * r], alj[r] = al[16 * J + lq + 4 * r];
+      for (int r = 0; r < 4; ++r) hk[r] = zs[16 * J + lq + 4 * r];
+      if (NT <= 6) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) alj[r] = al[16 * J + lq + 4 * r];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) arg[r] = (c[r] - hq) - hk[r];  // = -1/2 (((-2 c) + xs) + zs), utils/math.lua:82
       amp_exp_nonpos4(arg, tab, kv);
@@ -125,7 +139,7 @@ __global__ void __launch_bounds__(KP_THREADS) kpost_small_kernel(KpArgs a) {
       // and the four 14-deep chains run one after the other between the MFMAs
       asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mac[r] = __builtin_fma(kv[r], alj[r], mac[r]);
+      for (int r = 0; r < 4; ++r) mac[r] = __builtin_fma(kv[r], NT <= 6 ? alj[r] : al[16 * J + lq + 4 * r], mac[r]);
       // V[I] += L^-1[I][J] K*'[J] for the row strips I >= J; register q of the tile is the B operand of k-step q.  The
       // fragments of a k-step first (NT - J independent reads), then its MFMAs (NT - J independent chains)
 #pragma unroll

@@ -2169,6 +2169,61 @@ def test_small_problem_kernels_equal_the_general_schedule_bit_for_bit(ctx, orc, 
         ref.close()
 
 
+def test_small_problem_kernels_on_ragged_and_tiny_grids(ctx, orc, monkeypatch):
+    """The one-launch path at the edges of its shapes: one observation, a 64-block filled to the last row, one row into the second;
+    grids of 1, 2, 15, 16, 17 and 31 candidates (less than a 16-candidate strip, exactly one, one and a bit); one and three hyper
+    samples; EI and the confidence bound.  Bits of the general schedule, nominee of the oracle.  What the path does NOT take --
+    two response columns, d = 33 -- must come out of the general path unchanged (same call, same answer as the oracle)."""
+    ref = _diag_context(monkeypatch, B7_FIT_SMALL="0", B7_NLL_SMALL="2", B7_KPOST_SMALL="0")
+    try:
+        rng = np.random.default_rng(99)
+        for N, d in ((1, 1), (3, 2), (64, 4), (65, 4)):
+            X = rng.random((N, d))
+            Y = np.cos(2.0 * X.sum(1, keepdims=True)) + 0.05 * rng.normal(size=(N, 1))
+            ls = np.full(d, 0.4)
+            hyps = [{"lenscale_sq": ls * (1 + 0.1 * s), "amp": 0.9, "noise": 1e-2, "mean": 0.2} for s in range(3)]
+            for M in (1, 2, 15, 16, 17, 31):
+                Xh = rng.random((M, d))
+                outs = []
+                for c in (ctx, ref):
+                    c.gp_set_data(X, Y)
+                    c.grid_upload(Xh)
+                    p = c.gp_predict_hyp(ls, 0.9, 1e-2, 0.2, download=True)
+                    b1 = c.eval_nominate(hyps[:1], score="ei", fmin=[float(Y.min())])
+                    b3 = c.eval_nominate(hyps, score="cb")
+                    s3 = c.score_finish(1.0, download=True)[2]
+                    outs.append({"mean": p["mean"], "var": p["var"], "b1": np.array(b1), "b3": np.array(b3), "s3": s3})
+                for k in outs[0]:
+                    assert outs[0][k].tobytes() == outs[1][k].tobytes(), "N %d M %d: %s" % (N, M, k)
+                acc = np.zeros(M)
+                for h in hyps:
+                    m_o, v_o = orc.gp.predict(orc.gp.fit(X, Y, **h), Xh)
+                    orc.c.accumulate(acc, orc.c.cb(m_o, v_o))
+                orc.c.divide(acc, 3.0)
+                assert relerr(outs[0]["s3"], acc, floor=1e-6) < REL
+                top = np.sort(acc)[-2:] if M > 1 else np.array([-np.inf, acc[0]])
+                if top[1] - top[0] > 1e-6 * abs(top[1]):
+                    assert int(outs[0]["b3"][1]) == orc.c.argmax_first(acc)[0]
+        # outside the path's range: the same calls, through the general schedule
+        X, Xh = rng.random((20, 33)), rng.random((50, 33))
+        Y = np.sin(X.sum(1, keepdims=True))
+        ctx.gp_fit(X, Y, np.full(33, 4.0), 1.0, 1e-3, 0.0)
+        ctx.grid_upload(Xh)
+        mu, var = ctx.gp_predict()
+        mu_o, var_o = orc.gp.predict(orc.gp.fit(X, Y, np.full(33, 4.0), 1.0, 1e-3, 0.0), Xh)
+        assert relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+        X, Xh = rng.random((30, 3)), rng.random((40, 3))
+        Y2 = np.stack([np.sin(X.sum(1)), np.cos(X.sum(1))], axis=1)
+        ctx.gp_fit(X, Y2, [0.3] * 3, 1.0, 1e-3, 0.0)
+        ctx.grid_upload(Xh)
+        mu, var = ctx.gp_predict()
+        f2 = orc.gp.fit(X, Y2, [0.3] * 3, 1.0, 1e-3, 0.0)
+        mu_o, var_o = orc.gp.predict(f2, Xh)
+        assert mu.shape == (40, 2) and relerr(mu, mu_o, floor=1e-3 * np.abs(mu_o).max()) < REL and relerr(var, var_o) < REL
+    finally:
+        ref.close()
+
+
 def test_small_fit_kernel_hands_a_failed_pivot_to_the_jitter_schedule(ctx, orc):
     """Duplicated observations and no noise: gp_small_kernel reports the pivot, b7_gp_fit assembles K through the general front
     end and runs utils/math.lua:159-218's retries; b7_eval_nominate redoes the nomination per sample.  Jitter, first failing
