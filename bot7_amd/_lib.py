@@ -29,7 +29,7 @@ SYMBOLS = [
     "b7_group_grid_sobol", "b7_group_grid_random", "b7_group_grid_onesided", "b7_group_grid_upload", "b7_group_grid_shape", "b7_group_grid_download",
     "b7_group_grid_remove_rows", "b7_group_gp_set_data", "b7_group_eval_nominate", "b7_group_nominate_commit",
     "b7_ei_compute", "b7_cb_compute", "b7_argmax",
-    "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get",
+    "b7_timer_start", "b7_timer_stop", "b7_timer_ms", "b7_profile_enable", "b7_profile_reset", "b7_profile_get", "b7_persist_fallbacks",
 ]
 
 
@@ -176,6 +176,7 @@ def load(which=None):
         "b7_profile_enable": (i32, [vp, i32]),
         "b7_profile_reset": (i32, [vp]),
         "b7_profile_get": (i32, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64)]),
+        "b7_persist_fallbacks": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -412,7 +413,10 @@ class Context(object):
         nll = np.empty(B, dtype=np.float64)
         jit = np.empty(B, dtype=np.float64)
         info = np.empty(B, dtype=np.int32)
+        before = self._L.b7_persist_fallbacks(self._h)
         self._ck(self._L.b7_gp_nll_batch(self._h, B, _ptr(ls), _ptr(a), _ptr(nz), _ptr(m), _ptr(nll), _ptr(jit), _ptr(info)))
+        if self._L.b7_persist_fallbacks(self._h) != before:
+            self.fit_token += 1      # a timed-out hand-off was redone in the context's fit slot: whoever cached "fit is current" must refit
         return (nll, jit, info) if want_info else nll
 
     def gp_nll1(self, lenscale_sq, amp, noise, mean):
@@ -427,7 +431,10 @@ class Context(object):
         buf[0][:] = lenscale_sq
         buf[1][0], buf[2][0], buf[3][0] = amp, noise, mean
         p = buf[7]
+        before = self._L.b7_persist_fallbacks(self._h)
         self._ck(self._L.b7_gp_nll_batch(self._h, 1, p[0], p[1], p[2], p[3], p[4], p[5], p[6]))
+        if self._L.b7_persist_fallbacks(self._h) != before:
+            self.fit_token += 1
         return float(buf[4][0]), float(buf[5][0]), int(buf[6][0])
 
     def chol(self, src):

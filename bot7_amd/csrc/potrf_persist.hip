@@ -1053,7 +1053,7 @@ int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv,
     int helpers = c->cus / nb_here - 1;
     if (helpers > njobs) helpers = njobs;
     PArgs a = {};
-    a.fault_panel = -1;
+    a.fault_panel = c->persist_fault;  // -1 outside the diagnostic build
     a.K = K + b0 * nn;
     a.L = L + b0 * nn;
     a.dinv = dinv + (int64_t)b0 * n * NB;
@@ -1133,7 +1133,7 @@ int launch_nll_one(b7_ctx *c, const double *K, double *L, double *dinv, unsigned
   int njobs = 0;
   B7_TRY(persist_jobs(c, nb, 2, &jobs, &njobs));
   PArgs a = {};
-  a.fault_panel = -1;
+  a.fault_panel = c->persist_fault;  // -1 outside the diagnostic build
   a.K = K;
   a.L = L;
   a.dinv = dinv;
@@ -1164,5 +1164,5 @@ extern "C" int b7dbg_persist_stamps(b7_ctx *c, unsigned long long *out, int max_
 }
 #endif
 
-// diagnostics: persistent launches of this context that timed out on a hand-off and were redone by the launch schedule
-extern "C" int b7dbg_persist_aborts(b7_ctx *c) { return c ? c->persist_aborts : -1; }
+// persistent launches of this context that timed out on a hand-off and were redone by the launch schedule (include/bot7hip.h)
+extern "C" int b7_persist_fallbacks(b7_ctx *c) { return c ? c->persist_aborts : -1; }

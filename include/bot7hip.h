@@ -428,6 +428,12 @@ int b7_profile_enable(b7_ctx *ctx, int on);
 int b7_profile_reset(b7_ctx *ctx);
 int b7_profile_get(b7_ctx *ctx, const char *phase, double *ms_total, int64_t *launches);
 
+/* How many persistent launches of this context (the one-launch Cholesky of N > 128 observations) ran into a hand-off time-out
+ * -- the GPU was shared with somebody else's persistent kernel -- and were redone by the per-panel launch schedule (same bits).
+ * A host that keeps its own "the context's fit is current" flag compares the count around b7_gp_nll_batch: when it moved, the
+ * fallback used the context's fit slot (see there) and the next predict needs a new fit.  -1 for a null context. */
+int b7_persist_fallbacks(b7_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

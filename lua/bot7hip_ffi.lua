@@ -97,6 +97,7 @@ int b7_timer_ms(b7_ctx *ctx, int slot, float *ms_out);
 int b7_profile_enable(b7_ctx *ctx, int on);
 int b7_profile_reset(b7_ctx *ctx);
 int b7_profile_get(b7_ctx *ctx, const char *phase, double *ms_total, int64_t *launches);
+int b7_persist_fallbacks(b7_ctx *ctx);
 /* END generated */
 ]]
 

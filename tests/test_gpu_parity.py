@@ -1564,7 +1564,7 @@ def _two_schedules(monkeypatch):
 
 
 def _aborts(c):
-    return c._L.b7dbg_persist_aborts(c._h)
+    return c._L.b7_persist_fallbacks(c._h)
 
 
 @pytest.mark.parametrize("N,d,cols", [(2, 3, 1), (64, 6, 1), (100, 6, 1), (129, 6, 1), (256, 6, 7), (700, 32, 1),
@@ -1815,6 +1815,18 @@ def test_persistent_cholesky_times_out_into_the_launch_schedule(orc, monkeypatch
         # a matrix with fewer panels than the faulty one is unaffected
         r = persist.gp_fit(X_obs[:100], Y[:100], want_nll=True, **hyp)
         assert _aborts(persist) == 1 and np.isfinite(r["nll"]).all()
+        # the likelihood-only call: twice timed out -> evaluated in the context's fit slot by the launch schedule (the header's
+        # exception to "leaves the current fit alone"): same value, b7_persist_fallbacks moved, the binding bumped fit_token, and
+        # the next predict asks for a new fit
+        persist.gp_fit(X_obs, Y, **hyp)
+        launch.gp_set_data(X_obs, Y)
+        persist.gp_set_data(X_obs, Y)
+        tok, n0 = persist.fit_token, _aborts(persist)
+        a = launch.gp_nll_batch(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        b = persist.gp_nll_batch(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
+        assert np.array_equal(a, b) and _aborts(persist) > n0 and persist.fit_token > tok
+        with pytest.raises(bot7_amd.Bot7HipError):
+            persist.gp_predict()
     finally:
         launch.close()
         persist.close()
