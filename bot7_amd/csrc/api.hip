@@ -566,10 +566,10 @@ int b7_gp_set_opts(b7_ctx *c, const b7_gp_opts *o) {
 }
 
 // One factorisation attempt of K + extra*I; returns dpotrf-style info through *info.
-static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse);
+static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse, FactorNote *note = nullptr);
 void persist_gave_up(b7_ctx *c);
-static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse);
-static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse);
+static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse, FactorNote *note = nullptr);
+static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse, FactorNote *note = nullptr);
 
 // Y - mean on the device (padding rows zero): the sampler changes only the hypers, the data stay where they are
 __global__ void __launch_bounds__(256) resid_kernel(const double *__restrict__ y, double *__restrict__ r, int64_t nreal,
@@ -663,20 +663,20 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
   double *terms_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(c->info.p) + 16);
   const size_t blk_bytes = 16 + sizeof(double) * (nll_out ? 1 + ycols : 0);
   bool tail_done = false;
+  FactorNote note;  // what the last factorisation already did for the launch_alpha behind it
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (small && attempt == 0) {
       B7_TRY(launch_fit_small(c, 1, nullptr, ls_stage, ls_dev, (double *)c->w.p, (double *)c->zsc.p, (double *)c->zss.p, (double *)c->L.p,
                               (double *)c->Linv.p, (double *)c->dinv.p, (double *)c->alpha.p, (double *)c->resid.p, (int *)c->info.p,
                               nullptr));
       c->linv_done = true;
-      c->alpha_done = false;
       tail_done = true;
       if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
     } else {
-    B7_TRY(launch_potrf(c, 0.0, true));
+    B7_TRY(launch_potrf(c, 0.0, true, nullptr, &note));
     tail_done = c->linv_done;
     if (tail_done) {
-      B7_TRY(launch_alpha(c));
+      B7_TRY(launch_alpha(c, nullptr, 0, note));
       if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
     }
     }
@@ -702,13 +702,13 @@ static int fit_hyp_core(b7_ctx *c, const b7_hyp *hyp, double *nll_out, double *j
   if (info_first != 0) {
     c->fitted = false;
     if (small) B7_TRY(fit_front(c, hyp, ls_dev));  // K(X,X) for the retries (the one-launch fit does not keep it)
-    B7_TRY(jitter_retries(c, &jitter, true));
+    B7_TRY(jitter_retries(c, &jitter, true, &note));
     tail_done = false;
     predicted = false;
   }
   if (!tail_done) {
     B7_TRY(launch_trtri(c));
-    B7_TRY(launch_alpha(c));
+    B7_TRY(launch_alpha(c, nullptr, 0, note));
     if (nll_out) B7_TRY(launch_nll_terms(c, terms_dev));
     B7_HIP(c, hipMemcpyAsync(&blk, c->info.p, blk_bytes, hipMemcpyDeviceToHost, c->stream));
     B7_HIP(c, hipStreamSynchronize(c->stream));
@@ -1169,12 +1169,11 @@ int eval_enqueue(b7_ctx *c, int S, const b7_hyp *hyps, const b7_score_spec *spec
   } else {
     for (int s = 0; s < S; ++s) {
       B7_TRY(fit_front(c, &hyps[s], (const double *)c->bhyp.p + (size_t)s * d));
-      c->report_hint = static_cast<int *>(c->pin_eval_dev) + 4 * s;  // a one-block factorisation mirrors its report itself
-      const int rc_f = launch_potrf(c, 0.0, true);
-      c->report_hint = nullptr;
-      B7_TRY(rc_f);
+      int *report = static_cast<int *>(c->pin_eval_dev) + 4 * s;  // a one-block factorisation mirrors its report itself
+      FactorNote note;
+      B7_TRY(launch_potrf(c, 0.0, true, report, &note));
       if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
-      B7_TRY(launch_alpha(c, static_cast<int *>(c->pin_eval_dev) + 4 * s, 4));  // + this fit's pivot report, no copy launch
+      B7_TRY(launch_alpha(c, report, 4, note));  // + this fit's pivot report, no copy launch
       c->fitted = true;
       B7_TRY(predict_into(c, (const double *)c->grid[c->grid_cur].p, c->M, (double *)c->mu.p, (double *)c->var.p));
       c->predicted = true;
@@ -1285,10 +1284,10 @@ static void persist_restore(b7_ctx *c) {
   if (c->potrf_sched_saved == 3 && c->persist_aborts < 3) c->potrf_sched = 3;
 }
 
-static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse) {
+static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse, FactorNote *note) {
   int two[2] = {0, 0};
   for (int attempt = 0; attempt < 2; ++attempt) {
-    B7_TRY(launch_potrf(c, extra, with_inverse));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
+    B7_TRY(launch_potrf(c, extra, with_inverse, nullptr, note));  // factors (K + extra*I): eps goes on the ORIGINAL matrix, utils/math.lua:190
     B7_HIP(c, hipMemcpyAsync(two, c->info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     B7_HIP(c, hipStreamSynchronize(c->stream));
     if (two[1] == 0) break;
@@ -1302,17 +1301,17 @@ static int try_factor(b7_ctx *c, double extra, int *info, bool with_inverse) {
 
 // utils/math.lua:159-218 on c->K (N x N inside Npad x Npad): plain attempt, then the growing-jitter retries on
 // the ORIGINAL matrix; leaves L and dinv on the device.
-static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse) {
+static int chol_with_jitter(b7_ctx *c, double *jitter_out, int *info_first_out, bool with_inverse, FactorNote *note) {
   int info = 0;
-  B7_TRY(try_factor(c, 0.0, &info, with_inverse));
+  B7_TRY(try_factor(c, 0.0, &info, with_inverse, note));
   *info_first_out = info;
   *jitter_out = 0.0;
-  if (info != 0) B7_TRY(jitter_retries(c, jitter_out, with_inverse));
+  if (info != 0) B7_TRY(jitter_retries(c, jitter_out, with_inverse, note));
   return B7_OK;
 }
 
 // The retries of utils/math.lua:174-202 after a failed plain attempt.
-static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse) {
+static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse, FactorNote *note) {
   const int N = c->N;
   int info = 1;
   double jitter = 0.0;
@@ -1333,10 +1332,11 @@ static int jitter_retries(b7_ctx *c, double *jitter_out, bool with_inverse) {
         jitter = -1.0;
         B7_TRY(launch_set_identity(c));  // L = I, dinv = identity blocks
         c->linv_done = false;  // launch_trtri rebuilds inv(L) from this L and dinv
+        if (note) *note = FactorNote();  // ... and launch_alpha computes alpha from that inverse
         break;
       }
       eps = eps * c->opts.jitter_growth;  // :188
-      B7_TRY(try_factor(c, eps, &info, with_inverse));
+      B7_TRY(try_factor(c, eps, &info, with_inverse, note));
       if (info == 0) {
         jitter = eps;
         break;
@@ -1498,7 +1498,6 @@ int b7_gp_fantasize(b7_ctx *c, const double *X_pend, int P, int n, uint64_t seed
 }
 
 int b7_gp_append(b7_ctx *c, const double *x_new, const double *y_new) {
-  if (c) c->alpha_done = false;  // whatever the last factorisation left: this call computes alpha itself
   if (!c) return B7_ERR_INVALID;
   if (!c->fitted || c->model_kind != 0) return b7_fail(c, B7_ERR_STATE, "gp_append: no GP fit on this context");
   if (!x_new || !y_new) return b7_fail(c, B7_ERR_INVALID, "gp_append: NULL argument");
@@ -1686,9 +1685,10 @@ static int blr_fit_core(b7_ctx *c, const double *Y0, int N, int z, double alpha_
                           (double *)c->resid.p));
   int info_first = 0;
   double jitter = 0.0;
-  B7_TRY(chol_with_jitter(c, &jitter, &info_first, true));
+  FactorNote note;
+  B7_TRY(chol_with_jitter(c, &jitter, &info_first, true, &note));
   B7_TRY(launch_trtri(c));
-  B7_TRY(launch_alpha(c));
+  B7_TRY(launch_alpha(c, nullptr, 0, note));
   B7_HIP(c, hipStreamSynchronize(c->stream));
   if (nll_out) {
     // -log p(y | alpha, beta) = -[ z/2 log alpha + N/2 log beta - E(m) - 1/2 log|K| - N/2 log 2 pi ],
@@ -1844,9 +1844,10 @@ static int blr_enqueue_fit(b7_ctx *c, const b7_mlp *net, const double *X0, const
   B7_TRY(launch_blr_assemble(c, (const double *)c->W.p, (double *)c->K.p, z, zpad, alpha_prec, beta));
   B7_TRY(launch_gemv_rows(c, (const double *)c->tmpgrid.p, nk, (const double *)yvdev, nk, 0.0, 0, zpad, zpad,
                           (double *)c->resid.p));
-  B7_TRY(launch_potrf(c, 0.0, true));
+  FactorNote note;
+  B7_TRY(launch_potrf(c, 0.0, true, nullptr, &note));
   if (!c->linv_done) B7_TRY(launch_trtri(c));  // on a failed factor this inverts rubbish; the report discards it
-  B7_TRY(launch_alpha(c));
+  B7_TRY(launch_alpha(c, nullptr, 0, note));
   // the pivot report of the plain attempt, into the pinned fit-report block in stream order
   B7_HIP(c, hipMemcpyAsync(c->pinned, c->info.p, 16, hipMemcpyDeviceToHost, c->stream));
   c->fitted = true;

@@ -95,9 +95,6 @@ struct b7_ctx {
   int spin_us = 500;         // how long a call spins on a completion word in mapped host memory before it waits for the stream (B7_SPIN_US; 0: never)
   bool npad_small = true;    // N <= 64 (and <= 64 basis features) padded to ONE 64-block (B7_NPAD_SMALL=0: to 128)
   bool potrf_small = true;   // Npad == 64: factorisation + inverse (+ alpha) in one workgroup of one launch (blr_small.hip); B7_POTRF_SMALL=0 / any explicit B7_POTRF_SCHED: off
-  bool alpha_done = false;   // the last factorisation also produced alpha (launch_alpha has nothing left to do)
-  int *report_written = nullptr; // where the last one-block factorisation did mirror it
-  int *report_hint = nullptr; // where the next factorisation should mirror its pivot report (mapped host memory), or null
   bool blr_small = true;     // b7_blr_eval_nominate: the head for z <= 64 features in one workgroup of one launch (blr_small.hip)
   double fmin_scalar = 0.0;  // f_min of a single response column: a kernel argument of the EI kernels (launched with fmin_dev == nullptr), no staging copy
   bool acc_fresh = false;  // the accumulator stands for zeros that were never written: the next score launch onto it starts from 0.0
@@ -283,7 +280,16 @@ int launch_ksx(b7_ctx *c, const double *xq, int64_t row0, int64_t rows, int64_t 
                double *mu, int ycols);
 
 // potrf.hip
-int launch_potrf(b7_ctx *c, double extra, bool with_inverse);  // K + extra*I -> L, dinv, info (+ Linv, using W)
+// What a factorisation hands to the launch_alpha that follows it (the one-block kernel does more than factor): passed by the
+// caller from one to the other, not kept in the context -- a caller that changes the residual or the response columns in
+// between simply does not pass it on.
+struct FactorNote {
+  bool alpha_done = false;        // alpha (one response column) is already in c->alpha
+  int *report_written = nullptr;  // where the pivot report was mirrored (mapped host memory), or null
+};
+// K + extra*I -> L, dinv, info (+ Linv, using W).  report_hint: where a one-block factorisation should mirror its pivot report
+// itself (mapped host memory), or null; note (nullable): see FactorNote
+int launch_potrf(b7_ctx *c, double extra, bool with_inverse, int *report_hint = nullptr, FactorNote *note = nullptr);
 int launch_trtri(b7_ctx *c);           // L, dinv -> Linv (no-op when launch_potrf already built it)
 int launch_potrf_persist(b7_ctx *c, double extra, bool with_inverse);  // the same in one persistent launch (Npad <= 4096)
 int launch_nll_batch(b7_ctx *c, int B, const double *K, double *L, double *dinv, unsigned *flags, int *info,
@@ -318,7 +324,8 @@ int launch_fit_small(b7_ctx *c, int B, const double *hyp_dev, const double *hyp_
                      double *zss, double *L, double *Linv, double *dinv, double *alpha, double *resid, int *info_dev,
                      int *report_dev);
 // report_dev (nullable): device address of mapped host memory that receives the first report_words ints of the pivot report
-int launch_alpha(b7_ctx *c, int *report_dev = nullptr, int report_words = 0);  // resid, Linv -> alpha
+// resid, Linv -> alpha; report_dev (nullable): the pivot report's mirror; note: what the factorisation just before already did
+int launch_alpha(b7_ctx *c, int *report_dev = nullptr, int report_words = 0, const FactorNote &note = FactorNote());
 int launch_alpha_batch(b7_ctx *c, int B, const double *Linv, const double *resid, double *alpha, const int *report_src = nullptr,
                        int *report_dev = nullptr, int report_words = 0);  // B single-column fits
 int launch_fit_batch(b7_ctx *c, int B, const double *K, double *L, double *Linv, double *dinv, unsigned *flags, int *info);

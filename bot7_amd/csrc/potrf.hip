@@ -559,19 +559,18 @@ int launch_fantasy_factor(b7_ctx *c, double *S, double *dinv_tmp, int *info_dev)
 // of the diagonal-block and panel-solve kernels, see there), so it costs no launches and almost no time of its
 // own -- the factorisation is a chain of small dependent kernels that leaves most CUs idle.  Needs c->Linv and
 // c->W (n x n each).  Without it (b7_chol) only L and dinv are produced and launch_trtri is the way to inv(L).
-int launch_potrf(b7_ctx *c, double extra, bool with_inverse) {
-  c->alpha_done = false;
-  c->report_written = nullptr;
+int launch_potrf(b7_ctx *c, double extra, bool with_inverse, int *report_hint, FactorNote *note) {
+  if (note) *note = FactorNote();
   if (c->Npad == 64 && c->potrf_small && with_inverse && c->potrf_sched == 3 && c->inverse_inline) {
     // one 64-block: factorisation, inverse, pivot report and (one response column) alpha in one workgroup of one launch
     B7_TRY(b7_ensure(c, c->info, B7_INFO_BYTES));
     const bool one_col = c->ycols == 1 && c->yld == 1;
     B7_TRY(launch_potrf_small(c, 1, (const double *)c->K.p, (double *)c->L.p, (double *)c->Linv.p, (double *)c->dinv.p,
                               one_col ? (const double *)c->resid.p : nullptr, (double *)c->alpha.p, extra, (int *)c->info.p,
-                              c->report_hint, 0, 0, 0, 0, 4));
+                              report_hint, 0, 0, 0, 0, 4));
     c->linv_done = true;
-    c->alpha_done = one_col;
-    c->report_written = c->report_hint;
+    if (note) note->alpha_done = one_col, note->report_written = report_hint;
+    else if (one_col) { /* alpha was written as well; a caller that does not ask recomputes it: same bits */ }
     return B7_OK;
   }
   if (c->potrf_sched == 3 && c->Npad <= B7_PERSIST_NMAX && c->inverse_inline) return launch_potrf_persist(c, extra, with_inverse);
@@ -800,10 +799,9 @@ __global__ void copy_report_kernel(const int *__restrict__ src, int *__restrict_
 }
 }  // namespace
 
-int launch_alpha(b7_ctx *c, int *report_dev, int report_words) {
-  if (c->alpha_done) {  // the one-block factorisation produced alpha already (launch_potrf); only the report may be owed
-    c->alpha_done = false;  // good for the one launch_alpha that follows that factorisation (b7_gp_append recomputes alpha later)
-    if (report_dev && report_dev != c->report_written) {
+int launch_alpha(b7_ctx *c, int *report_dev, int report_words, const FactorNote &note) {
+  if (note.alpha_done) {  // the one-block factorisation produced alpha already (launch_potrf); only the report may be owed
+    if (report_dev && report_dev != note.report_written) {
       hipLaunchKernelGGL(copy_report_kernel, dim3(1), dim3(64), 0, c->stream, (const int *)c->info.p, report_dev, report_words);
       B7_HIP(c, hipGetLastError());
     }
