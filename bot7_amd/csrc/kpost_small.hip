@@ -197,8 +197,13 @@ template <int DPAD, int NT>
 int kp_launch(b7_ctx *c, const KpArgs &a) {
   B7_TRY(ensure_kp_table(c));
   const size_t lds = sizeof(double) * (size_t)kp_lds_doubles<DPAD>(NT);
-  B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kpost_small_kernel<DPAD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+  // the opt-in to > 64 KiB of dynamic LDS is per device: once per instantiation AND device (a process may hold contexts on several)
+  static bool attr_done[64] = {false};
+  if (c->device >= 64 || !attr_done[c->device]) {
+    B7_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kpost_small_kernel<DPAD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    if (c->device < 64) attr_done[c->device] = true;
+  }
   // workgroups per CU: two where the instance's registers (<= 128: four waves per SIMD) and LDS allow it, else one; the CUs'
   // slots are split between the S fits; never more workgroups of a fit than it has strips for their waves
   static int per_cu_cache = 0;  // per instantiation

@@ -421,7 +421,9 @@ int launch_score_finish_slot(b7_ctx *c, const b7_ctx::PendingScore &ps, double *
                              unsigned *host_done) {
   PhaseScope scope(c, "score");
   // (one-wave blocks for small grids -- 313 instead of 79 workgroups for 2e4 candidates -- measured SLOWER: 145 vs 139 us per
-  // nomination at N = 100, S = 10; the last block's pass over four times as many partials costs more than the spread saves)
+  // nomination at N = 100, S = 10; the last block's pass over four times as many partials costs more than the spread saves.
+  // Likewise the S scores of a candidate on S threads side by side, parked in LDS and added in order by one of them, over 512
+  // blocks: 137 vs 132 us.  The kernel's 15 us are launch, ticket and the last block's pass, not the ten scores in a row)
   const int threads = 256;
   const int nb = nblocks(c, M);
   B7_TRY(b7_ensure(c, c->part, sizeof(Best) * (size_t)(nb + 1)));
