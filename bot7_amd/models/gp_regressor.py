@@ -101,6 +101,46 @@ class gp_regressor(abstract):
         self.nEvals = getattr(self, "nEvals", 0) + 1
         return -float(self.nll(X_obs, Y_obs, self._from_theta(theta))[0])
 
+    def _make_resident(self, X, Y):
+        """The observations on the device (b7_gp_set_data), once per data set: a cheap look first (addresses, shapes, the last
+        entries, the context's fit token), the content hash only when that differs."""
+        fast = (X.__array_interface__["data"][0], X.shape, Y.__array_interface__["data"][0], float(X[-1, -1]), float(Y[-1, 0]),
+                self.ctx.fit_token)
+        if getattr(self, "_resident_fast", None) != fast:
+            key = self._data_key(X, Y)
+            if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
+                self.ctx.gp_set_data(X, Y)
+                self._resident_key = (key, self.ctx.fit_token)
+            self._resident_fast = fast[:-1] + (self.ctx.fit_token,)
+
+    def _density(self, X, Y):
+        """log_posterior as the sampler's density for ONE update (X, Y: the float64 arrays sample_hypers holds): the same
+        statements, with what cannot change between two evaluations of an update -- the bounds, the residency of the data --
+        done once.  At the reference's default sizes a density evaluation is a 20-30 us library call; the per-call
+        bookkeeping of log_posterior + nll was another 12."""
+        if Y.shape[1] != 1:
+            return lambda t, _args: self.log_posterior(t, X, Y)
+        lo, hi = self._bounds(X, Y)
+        d = X.shape[1]
+        self._make_resident(X, Y)
+        ctx = self.ctx
+        one = getattr(ctx, "gp_nll1", None)
+
+        def f(t, _args):
+            t = np.asarray(t, dtype=np.float64).ravel()
+            if not ((t >= lo) & (t <= hi)).all():      # also NaN: it fails both comparisons
+                return -np.inf
+            self.nEvals = getattr(self, "nEvals", 0) + 1
+            ls, amp, noise, mean = np.exp(t[:d]), float(np.exp(t[d])), float(np.exp(t[d + 1])), float(t[d + 2])
+            if one is not None:
+                v, jit, info = one(ls, amp, noise, mean)
+            else:
+                nll, jit, info = ctx.gp_nll_batch(ls, amp, noise, mean, want_info=True)
+                v, jit, info = float(nll[0]), float(jit[0]), int(info[0])
+            self.last_fit = {"nll": v, "jitter": jit, "info": info}
+            return -v
+        return f
+
     def _samplers(self):
         from .abstract import sampler_registry
         name = self.config.get("sampler", "slice")
@@ -132,7 +172,7 @@ class gp_regressor(abstract):
                 self.hyp["noise"] = np.exp(self._bounds(X, Y)[0][-2])
             theta = self._to_theta(self.hyp)
             n_updates = 1 if state else int(self.config.get("nBurnin", 0))
-            f = lambda t, _args: self.log_posterior(t, X, Y)  # noqa: E731
+            f = self._density(X, Y)
             for _ in range(n_updates):
                 theta = self._sampler.sample(f, theta.reshape(1, -1), dict(self._sopt, nSamples=1), None)[0]
             self.hyp = self._from_theta(theta)
@@ -254,14 +294,7 @@ class gp_regressor(abstract):
             # and for N <= 128 one workgroup of one launch (b7_gp_nll_batch)
             # (the content hash is taken once per array pair, not per evaluation: the sampler calls this ~70 times a trial with the
             # same two arrays)
-            fast = (X.__array_interface__["data"][0], X.shape, Y.__array_interface__["data"][0], float(X[-1, -1]), float(Y[-1, 0]),
-                    self.ctx.fit_token)
-            if getattr(self, "_resident_fast", None) != fast:
-                key = self._data_key(X, Y)
-                if getattr(self, "_resident_key", None) != (key, self.ctx.fit_token):
-                    self.ctx.gp_set_data(X, Y)
-                    self._resident_key = (key, self.ctx.fit_token)
-                self._resident_fast = fast[:-1] + (self.ctx.fit_token,)
+            self._make_resident(X, Y)
             if hasattr(self.ctx, "gp_nll1"):
                 v, jit, info = self.ctx.gp_nll1(hyp["lenscale_sq"], hyp["amp"], hyp["noise"], hyp["mean"])
                 self.last_fit = {"nll": np.array([v]), "jitter": jit, "info": info}

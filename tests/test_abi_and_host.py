@@ -258,3 +258,21 @@ print("swept", len(_lib.SYMBOLS))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stderr[-800:])
     assert "swept %d" % len(_lib.SYMBOLS) in out.stdout
+
+
+def test_default_regime_loop_on_the_oracle_context_is_deterministic():
+    """harness/default_regime.py (the trial loop bench.py --workload default times) on oracle/hostctx.py, the device's stand-in:
+    six trials of the reference's default experiment on a 2000-candidate grid, twice -- same nominees, same responses, same
+    hyper draws; every nominee a distinct 1-based index into the ORIGINAL grid; the per-trial clock split is there."""
+    from harness import default_regime as dr
+    from oracle.hostctx import OracleContext
+    runs = [dr.run(OracleContext(), budget=6, grid_size=2000) for _ in range(2)]
+    a, b = runs
+    assert a["nominees"] == b["nominees"] and len(a["nominees"]) == 6 and len(set(a["nominees"])) == 6
+    assert all(1 <= i <= 2000 for i in a["nominees"])
+    assert np.array_equal(a["Y"], b["Y"]) and a["X"].shape == (6, 6)
+    assert len(a["draws"]) == 6 and all(np.array_equal(x, y) for x, y in zip(a["draws"], b["draws"]))
+    assert [len(v) for v in a["draws"]] == [0, 0, 10, 10, 10, 10]      # nInitial = 2 random picks first, then ten hyper vectors a trial
+    assert dr.agreement(a, b) == (6, 0.0)
+    split = dr.summarise(a["per_trial"])
+    assert split["model_based_trials"] == 4 and split["nll_calls"] > 40

@@ -968,6 +968,33 @@ def test_dngo_model_in_bayesopt_loop(ctx, orc):
     assert bot.observed.shape == (7, 6)
 
 
+def test_default_regime_device_loop_follows_the_oracle_loop(ctx):
+    """The reference's default experiment (hartmann6, 2e4 Sobol candidates, nInitial 2, S = 10 slice-sampled hypers, EI) as
+    bench.py --workload default runs it, 14 trials: the device loop (b7_gp_nll_batch per density evaluation, b7_eval_nominate,
+    b7_nominate_commit) and the oracle loop (oracle/hostctx.py behind the same harness code and seeds) must nominate the same
+    candidates and draw the same hypers -- the sampler sees the densities only through comparisons.  Then the bench line itself
+    at a budget of 10.  (GP algebra: parity unpinned.)"""
+    import json
+    import subprocess
+    import sys
+    from harness import default_regime as dr
+    from oracle.hostctx import OracleContext
+    g = dr.run(ctx, budget=14)
+    o = dr.run(OracleContext(), budget=14)
+    assert g["nominees"] == o["nominees"] and len(g["nominees"]) == 14
+    same, worst = dr.agreement(g, o)
+    assert same == 14 and worst < 1e-9
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "default", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=root, B7_DEFAULT_BUDGET="10"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "trials/s" and line["n_gpus"] == 1 and line["value"] > 0 and line["vs_baseline"] is None
+    assert line["roofline"]["bound"] == "dependent chain" and line["roofline_nominate"]["frac_of_pipe"] > 0
+    assert line["cpu_baseline"]["kind"] == "port" and line["parity"]["leading_trials_with_the_same_nominee"] == 10
+    assert line["config"]["workload"].startswith("default")
+
+
 def test_two_ranks_share_the_gpu_and_agree_with_one(ctx):
     """The N>1 path end to end on real device contexts: two ranks (gloo exchange, both on cuda:0) each own half of
     a 131072-candidate Sobol grid; the exchanged winner must be the single-process winner over the whole grid."""
