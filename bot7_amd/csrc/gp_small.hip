@@ -281,8 +281,9 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
     // (the half norms follow below, once they are in LDS), and this fit's hypers where the kernels downstream find them
     const int dpad = a.dpad;
     double *zo = a.zsc + (size_t)b * npad * dpad;
+    const int dsh = __builtin_ctz(dpad);  // dpad is 4, 8, 16 or 32
     for (int e = tid; e < npad * dpad; e += GS_THREADS) {
-      const int i = e / dpad, k = e - i * dpad;
+      const int i = e >> dsh, k = e & (dpad - 1);
       zo[e] = obs[i * OLD + k] * w[k];
     }
     if (tid < dpad) a.w[(size_t)b * dpad + tid] = w[tid];
