@@ -193,13 +193,21 @@ __device__ __forceinline__ void lower_tile(int q, int &it, int &jt) {
 // a 64 x 64 image (row stride DLD) -> global rows of leading dimension ld; lower: entries above the diagonal become zero
 __device__ __forceinline__ void store_block(const double *__restrict__ img, double *__restrict__ dst, int64_t ld, bool lower, int t0,
                                             int nt) {
-  for (int e = t0; e < NB * NB; e += nt) {
-    const int i = e >> 6, j = e & 63;
-    dst[(int64_t)i * ld + j] = (!lower || j <= i) ? img[i * DLD + j] : 0.0;
+  // two columns (16 bytes) per lane and instruction: a wave stores 1 KiB at a time (images and destinations are 16-byte
+  // aligned: DLD and every leading dimension are even)
+  for (int e = t0; e < NB * NB / 2; e += nt) {
+    const int i = e >> 5, j = 2 * (e & 31);
+    d2_t v = *reinterpret_cast<const d2_t *>(img + i * DLD + j);
+    if (lower) {
+      if (j > i) v[0] = 0.0;
+      if (j + 1 > i) v[1] = 0.0;
+    }
+    *reinterpret_cast<d2_t *>(dst + (int64_t)i * ld + j) = v;
   }
 }
 __device__ __forceinline__ void store_zero_block(double *__restrict__ dst, int64_t ld, int t0, int nt) {
-  for (int e = t0; e < NB * NB; e += nt) dst[(int64_t)(e >> 6) * ld + (e & 63)] = 0.0;
+  const d2_t zero = {0.0, 0.0};
+  for (int e = t0; e < NB * NB / 2; e += nt) *reinterpret_cast<d2_t *>(dst + (int64_t)(e >> 5) * ld + 2 * (e & 31)) = zero;
 }
 
 // TWO: N > 64 (two 64-blocks).  A template parameter, not a run-time test: the kernel runs every instruction once, out of a cold
@@ -231,7 +239,11 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
   const double amp = hyp[(size_t)B * d + b], noise = hyp[(size_t)B * (d + 1) + b], mean = hyp[(size_t)B * (d + 2) + b];
   GS_STAMP(0);
   if (tid < 4) inf[tid] = 0;
-  if (tid < 32) w[tid] = tid < d ? 1.0 / ls[tid] : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
+  double lsv = 0.0;  // this lane's lengthscale (a batch's hypers sit in mapped HOST memory: every read is a trip over PCIe)
+  if (tid < 32) {
+    if (tid < d) lsv = ls[tid];
+    w[tid] = tid < d ? 1.0 / lsv : 0.0;  // inv_ls = ones:cdiv(lenscale), utils/math.lua:72
+  }
   if (tid < 128) {
     tab[tid] = amp * exp2_tab_gs[tid];
     r[tid] = tid < N ? a.y[tid] - mean : 0.0;
@@ -287,9 +299,9 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       zo[e] = obs[i * OLD + k] * w[k];
     }
     if (tid < dpad) a.w[(size_t)b * dpad + tid] = w[tid];
-    if (a.hyp_out && tid < d + 3) {
+    if (a.hyp_out && tid < d + 3) {  // (from the registers that hold them already, not read a second time)
       const size_t at = tid < d ? (size_t)b * d + tid : (size_t)B * (d + (tid - d)) + b;
-      a.hyp_out[at] = hyp[at];
+      a.hyp_out[at] = tid < d ? lsv : (tid == d ? amp : (tid == d + 1 ? noise : mean));
     }
   }
   lds_barrier();
@@ -588,24 +600,28 @@ __global__ void __launch_bounds__(GS_THREADS) gp_small_kernel(GsArgs a, GsInline
       // butterfly (xor 32, 16, ..., 1) adds the 64 partial sums.  Here a THREAD takes a row and walks the same binary tree over
       // its 64 partial sums in registers -- level o adds element l and l + o for l < o, exactly the pairs lane 0 of the
       // butterfly sees -- so the bits are the same and nothing crosses lanes (192 ds_bpermute per wave took 6 us).
-      if (tid < 128) {
-        const int row = tid;
-        const double *l0 = row < NB ? B3 + row * DLD : B2 + (row - NB) * DLD;  // columns 0..63 of the row
-        const double *l1 = B0 + (row < NB ? 0 : row - NB) * DLD;                // columns 64..127 (rows >= 64)
-        // no "k <= row" tests: the images hold +0.0 above the diagonals, and fma(0, r_k, s) = s (a lane-divergent branch per
-        // column cost 12 us here); rows 0..63 (wave 0) have no second column block at all
-        double p[64];
+      {
+        // ... and four threads take a row: thread q of the quad the columns l = q (mod 4), whose partial sums meet each other
+        // at every level down to o = 4 inside that thread (l and l + o are the same residue), the last two levels -- (0, 2),
+        // (1, 3), then (0, 1) -- across the quad.  The same tree, a quarter of the time, all eight waves
+        const int row = tid >> 2, q = tid & 3;
+        const double *l0 = (row < NB ? B3 + row * DLD : B2 + (row - NB) * DLD) + q;  // columns 0..63 of the row
+        const double *l1 = B0 + (row < NB ? 0 : row - NB) * DLD + q;                  // columns 64..127 (rows >= 64)
+        double p[16];
 #pragma unroll
-        for (int k = 0; k < 64; ++k) p[k] = __builtin_fma(l0[k], r[k], 0.0);
-        if (wave == 1) {
+        for (int m = 0; m < 16; ++m) p[m] = __builtin_fma(l0[4 * m], r[4 * m + q], 0.0);
+        if (wave >= 4) {  // rows 64..127
 #pragma unroll
-          for (int k = 0; k < 64; ++k) p[k] = __builtin_fma(l1[k], r[NB + k], p[k]);
+          for (int m = 0; m < 16; ++m) p[m] = __builtin_fma(l1[4 * m], r[NB + 4 * m + q], p[m]);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
+        for (int o = 8; o > 0; o >>= 1)
 #pragma unroll
-          for (int l = 0; l < o; ++l) p[l] = p[l] + p[l + o];
-        tv[row] = p[0];
+          for (int m = 0; m < o; ++m) p[m] = p[m] + p[m + o];
+        double v = p[0];
+        v = v + __shfl_xor(v, 2);
+        v = v + __shfl_xor(v, 1);
+        if (q == 0) tv[row] = v;
       }
       GS_STAMP(20);
       lds_barrier();
