@@ -53,7 +53,7 @@ GPU_CLOCK_HZ = 2.4e9           # shader clock under load (profiles/r04_post_cloc
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
 SOBOL_SKIP = 2                 # config.skip of the pool: see "Inputs" above
 PMC_SUMMARIES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01z_pmc_summary.json")  # newest first
-KSX_PMC_BY_CLASS = "r03_ksx_pmc_by_class.json"   # instruction counts of ksx_kernel per width class (covar.hip unchanged since)
+KSX_PMC_BY_CLASS = "r04_ksx_pmc_by_class.json"   # instruction counts of ksx_kernel per width class (tools/ksx_pmc.sh; covar.hip unchanged since round 3)
 
 
 def parse():
