@@ -126,10 +126,19 @@ class gp_regressor(abstract):
         ctx = self.ctx
         one = getattr(ctx, "gp_nll1", None)
 
+        data_key = self._resident_key
+
         def f(t, _args):
             t = np.asarray(t, dtype=np.float64).ravel()
             if not ((t >= lo) & (t <= hi)).all():      # also NaN: it fails both comparisons
                 return -np.inf
+            # the point a slice update starts from is the point the previous update ended on, whose density was the last thing
+            # evaluated (samplers/slice.lua:106 after :134-164): the same vector under the same data is not sent to the device
+            # again -- a pure function of both, so the value is the one a second evaluation would return, bit for bit
+            tb = t.tobytes()
+            memo = getattr(self, "_density_memo", None)
+            if memo is not None and memo[0] is data_key and memo[1] == tb:
+                return memo[2]
             self.nEvals = getattr(self, "nEvals", 0) + 1
             ls, amp, noise, mean = np.exp(t[:d]), float(np.exp(t[d])), float(np.exp(t[d + 1])), float(t[d + 2])
             if one is not None:
@@ -138,6 +147,7 @@ class gp_regressor(abstract):
                 nll, jit, info = ctx.gp_nll_batch(ls, amp, noise, mean, want_info=True)
                 v, jit, info = float(nll[0]), float(jit[0]), int(info[0])
             self.last_fit = {"nll": v, "jitter": jit, "info": info}
+            self._density_memo = (data_key, tb, -v)
             return -v
         return f
 
@@ -170,12 +180,16 @@ class gp_regressor(abstract):
                 self._sopt.setdefault("width", 0.5)
             if self.config.get("noiseless") and self.hyp["noise"] <= 0.0:
                 self.hyp["noise"] = np.exp(self._bounds(X, Y)[0][-2])
-            theta = self._to_theta(self.hyp)
+            # the chain's state is theta itself: as long as nobody replaced self.hyp, the next update starts from the very vector
+            # the last one returned (not from log(exp(theta)), which differs in the last bits) -- and the density there is known
+            kept = getattr(self, "_chain_state", None)
+            theta = kept[0] if kept is not None and kept[1] is self.hyp else self._to_theta(self.hyp)
             n_updates = 1 if state else int(self.config.get("nBurnin", 0))
             f = self._density(X, Y)
             for _ in range(n_updates):
                 theta = self._sampler.sample(f, theta.reshape(1, -1), dict(self._sopt, nSamples=1), None)[0]
             self.hyp = self._from_theta(theta)
+            self._chain_state = (theta, self.hyp)
         h = self.hyp
         return np.concatenate([h["lenscale_sq"], [h["amp"], h["noise"], h["mean"]]])
 

@@ -137,8 +137,15 @@ function model:log_posterior(theta, X_obs, Y_obs)
   local theta = theta:view(-1)
   local lo, hi = self:bounds(X_obs, Y_obs)
   if theta:lt(lo):any() or theta:gt(hi):any() or theta:ne(theta):any() then return -math.huge end
+  -- the point a slice update starts from is the point the previous update ended on, whose density was the last thing evaluated
+  -- (samplers/slice.lua:106 after :134-164): the same vector under the same data is not sent to the device again
+  self:stage_data(X_obs, Y_obs)
+  local memo = self._density_memo
+  if memo and memo.data == self._data and memo.theta:equal(theta) then return memo.value end
   self.nEvals = self.nEvals + 1
-  return -self:nll(X_obs, Y_obs, from_theta(theta))
+  local value = -self:nll(X_obs, Y_obs, from_theta(theta))
+  self._density_memo = {data = self._data, theta = theta:clone(), value = value}
+  return value
 end
 
 -- config.chains = C > 1: C chains of the reference's own slice sampler advance in lock step.  Each chain runs inside a
@@ -221,7 +228,10 @@ function model:sample_hypers(X_obs, Y_obs, _, _, state) -- bots/bayesopt.lua:68 
       local lo = self:bounds(X_obs, Y_obs)
       self.hyp.noise = math.exp(lo[X_obs:size(2) + 2])
     end
-    local theta     = to_theta(self.hyp)
+    -- the chain's state is theta itself: as long as nobody replaced self.hyp, the next update starts from the very vector the
+    -- last one returned (not from log(exp(theta))), where the density is known (log_posterior's memo)
+    local kept      = self._chain_state
+    local theta     = (kept and kept.hyp == self.hyp) and kept.theta or to_theta(self.hyp)
     local n_updates = state and 1 or (self.config.nBurnin or 0)
     local f = function(t, _) return self:log_posterior(t, X_obs, Y_obs) end
     self.sopt.nSamples = 1
@@ -229,6 +239,7 @@ function model:sample_hypers(X_obs, Y_obs, _, _, state) -- bots/bayesopt.lua:68 
       theta = self.sampler.sample(f, theta:view(1, -1), self.sopt, nil)[1]  -- samplers/slice.lua:51-89
     end
     self.hyp = from_theta(theta)
+    self._chain_state = {theta = theta:clone(), hyp = self.hyp}
   end
   local h = self.hyp
   return torch.cat(h.lenscale_sq, torch.DoubleTensor{h.amp, h.noise, h.mean})
