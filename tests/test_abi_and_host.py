@@ -276,3 +276,48 @@ def test_default_regime_loop_on_the_oracle_context_is_deterministic():
     assert dr.agreement(a, b) == (6, 0.0)
     split = dr.summarise(a["per_trial"])
     assert split["model_based_trials"] == 4 and split["nll_calls"] > 40
+
+
+def test_density_memo_follows_the_data_and_the_point():
+    """bot7_amd.models.gp_regressor's sampler density remembers its last evaluation (a slice update starts where the previous one
+    ended): the same point under the same data is answered without a library call, the same point under NEW data is not, and a
+    hyper table put in from outside restarts the chain from it."""
+    import bot7_amd
+    from harness import default_regime  # noqa: F401  (registers the sampler the model mirror looks up)
+
+    class Ctx(object):
+        fit_token, calls, sets = 0, 0, 0
+
+        def gp_set_data(self, X, Y):
+            self.sets += 1
+            self._data_d = X.shape[1]
+            self._bias = float(Y.sum())
+
+        def gp_nll1(self, ls, amp, noise, mean):
+            self.calls += 1
+            return (float(np.sum(np.log(ls))) + self._bias, 0.0, 0)
+
+    ctx = Ctx()
+    m = bot7_amd.models.gp_regressor({"sample": True, "nBurnin": 0, "seed": 3}, context=ctx)
+    rng = np.random.default_rng(5)
+    X, Y = rng.random((20, 3)), rng.normal(size=(20, 1))
+    m.init(X, Y)
+    f = m._density(X, Y)
+    t = m._to_theta(m.hyp)
+    a = f(t, None)
+    assert ctx.calls == 1 and f(t.copy(), None) == a and ctx.calls == 1          # same point, same data: no call
+    a2 = f(t + 1e-3, None)
+    assert a2 != a and ctx.calls == 2                                            # another point: a call
+    X2, Y2 = np.vstack([X, rng.random((1, 3))]), np.vstack([Y, [[0.7]]])
+    f2 = m._density(X2, Y2)
+    b = f2(t + 1e-3, None)                                                        # the memo's point, but new data: a call
+    assert ctx.calls == 3 and ctx.sets == 2 and b != a2
+    # the chain continues from the vector it returned, bit for bit, unless somebody replaced the hyper table
+    v1 = m.sample_hypers(X2, Y2, None, None, True)
+    kept = m._chain_state[0].copy()
+    n0 = ctx.calls
+    m.sample_hypers(X2, Y2, None, None, True)
+    assert ctx.calls > n0
+    m.hyp = m.parse_hypers(v1)
+    m.sample_hypers(X2, Y2, None, None, True)                                     # starts from log(exp(.)) of v1 again: fine, just not the memo
+    assert np.all(np.isfinite(m._chain_state[0])) and kept.shape == m._chain_state[0].shape
