@@ -383,7 +383,11 @@ def run_group(args):
     elif args.virtual_ranks:
         devices = [0] * G
     else:
-        sys.exit("bench.py --gpus %d: %d device(s) visible; pass --virtual-ranks to rehearse the group layout on one" % (G, ndev))
+        # fewer devices than ranks and no launcher: do not exit -- the group runs with its members sharing device 0 (a rehearsal:
+        # they time-share the GPU, so the value is one device's), and the line says so in config.parallelism / config.devices
+        sys.stderr.write("bench.py --gpus %d: %d device(s) visible -- running the single-process group as %d VIRTUAL ranks on device 0\n"
+                         % (G, ndev, G))
+        devices = [0] * G
     lib = "diag" if os.environ.get("B7_GROUP_EXCHANGE") == "rccl" else None   # forcing the grouped call for virtual ranks: diagnostic build
     g = bot7_amd.Group(devices, lib=lib)
     ginfo = g.info()
