@@ -177,7 +177,7 @@ def pmc_traffic(rows_per_launch, N):
     return None, None
 
 
-def run_default(args):
+def run_default(args, ctx=None, emit=True, cpu_seconds=None):
     """bench.py --workload default: the reference's own default experiment as a whole trial loop (harness/default_regime.py):
     hartmann6, d = 6, 2e4 Sobol candidates, budget 100 (N <= 100), nInitial 2, nSamples 10 slice-sampled hyper vectors per
     nomination, EI.  One step = one experiment; `value` = trials/s over the whole experiments (objective evaluations, a closed
@@ -187,7 +187,9 @@ def run_default(args):
     import bot7_amd
     from harness import default_regime as dr
     d, N, M, obj_name, score = WORKLOADS["default"]
-    ctx = bot7_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = bot7_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
     info = ctx.device_info()
     budget = int(os.environ.get("B7_DEFAULT_BUDGET", "100"))
     for _ in range(args.warmup):
@@ -312,7 +314,7 @@ def run_default(args):
             limiter = threadpool_limits(limits=cores)
         except Exception:
             limiter = None
-        cap_s = float(os.environ.get("B7_DEFAULT_CPU_SECONDS", "40"))
+        cap_s = float(cpu_seconds if cpu_seconds is not None else os.environ.get("B7_DEFAULT_CPU_SECONDS", "40"))
         t0 = time.perf_counter()
         stop = {"n": 0}
 
@@ -354,13 +356,18 @@ def run_default(args):
                           "gpu_faster_per_trial_from_N": cross,
                           "note": "oracle: GP algebra parity unpinned (no reference fixture; DESIGN.md section 2)"}
         if same < min(n_cpu, len(g["nominees"])):
-            print(json.dumps(line))
-            sys.exit("default regime: the GPU's nominee sequence leaves the oracle-driven loop at trial %d" % (same + 1))
+            line["parity"]["failed_at_trial"] = same + 1
+            if emit:
+                print(json.dumps(line))
+                sys.exit("default regime: the GPU's nominee sequence leaves the oracle-driven loop at trial %d" % (same + 1))
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line))
-    sys.stdout.flush()
-    ctx.close()
+    if emit:
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if own_ctx:
+        ctx.close()
+    return line
 
 
 def run_group(args):
@@ -919,6 +926,25 @@ def main():
                 c["winner_oracle_confirmed_on_window"] = bool(chk["matches_cpu_argmax"] and chk["is_the_global_winner"])
                 c["window_rows"] = a2.cpu_sample
             line["configs"][name] = c
+        # ---- and the reference's OWN default experiment (--workload default), compactly: one timed experiment of 100 trials, the
+        # oracle behind the same driver for a few seconds (its first ~40 trials: the nominee sequence is the parity check)
+        a3 = copy.copy(args)
+        a3.steps, a3.warmup, a3.no_cpu_baseline = 1, 1, False
+        with quiet_stdout():
+            l3 = run_default(a3, ctx=ctx, emit=False, cpu_seconds=4.0)
+        last = sorted(l3["kernels_by_N"], key=int)[-1]
+        line["default_regime"] = {
+            "workload": "python bench.py --workload default: hartmann6 d = 6, 20000 Sobol candidates, budget 100, nSamples 10, EI; a whole trial "
+                        "loop (slice sampler on the host, b7_gp_nll_batch per density evaluation, b7_eval_nominate, b7_nominate_commit)",
+            "value": l3["value"], "unit": l3["unit"], "ms_per_trial_at_N": {k: v["trial_ms"] for k, v in l3["ms_per_trial"]["at_N"].items()},
+            "library_calls_per_experiment": l3["ms_per_trial"]["nll_calls"], "at_N_%s" % last: l3["kernels_by_N"][last],
+            "likelihood_kernel_frac_of_chain_floor": l3["roofline"]["frac_of_floor"],
+            "fused_posterior_frac_of_pipe": l3["roofline_nominate"]["frac_of_pipe"],
+            "cpu_baseline": {k: l3["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "trials")},
+            "parity": l3["parity"]}
+        if l3["parity"].get("failed_at_trial"):
+            print(json.dumps(line))
+            sys.exit("default regime: the GPU's nominee sequence leaves the oracle-driven loop at trial %d" % l3["parity"]["failed_at_trial"])
     if rank == 0:
         print(json.dumps(line))
     sys.stdout.flush()
