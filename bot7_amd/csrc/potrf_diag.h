@@ -167,6 +167,11 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
   if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime()
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
+  // 16-blocks that hold anything (nlive): a block row i >= nl of the factor is e_i' -- zero left of its diagonal -- so every
+  // product below whose left operand is such a row block adds exact zeros to what is already there (+0.0 in X, the identity
+  // in A: the caller's images) and is left out; T's tiles for those rows are written as zeros (its storage is scratch).
+  // nlive = 64: nl = 4, nothing changes.
+  const int nl = (nlive + 15) >> 4;
   for (int kb = 0; kb < 4; ++kb) {
     const int o = kb * 16;
     if (VAR >= 1 && wave == 0 && o >= nlive) {
@@ -269,10 +274,10 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       const int ko = o - 16;
       if (kb == 1) {
         const int i = wave == 1 ? 2 : 3, j = wave == 3 ? 3 : 2;
-        block16_update(A, i, j, ko, lr, lq);
+        if (i < nl) block16_update(A, i, j, ko, lr, lq);
       } else if (kb == 2 && wave == 1) {
-        block16_update(A, 3, 3, ko, lr, lq);
-      } else if (kb == 2 && wave == 2) {
+        if (3 < nl) block16_update(A, 3, 3, ko, lr, lq);
+      } else if (kb == 2 && wave == 2 && 1 < nl) {
         // inverse doubling 16 -> 32 of the pair (0,1): X_10 = -inv(L_11) * (L_10 * inv(L_00)); its inputs are final
         d4_t t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -288,10 +293,12 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
         for (int q = 0; q < (wave == 1 ? 2 : 1); ++q) {
           const int ti = wave == 1 ? 0 : 1, tj = wave == 1 ? q : wave - 2;
           d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+          if (2 + ti < nl) {
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
-            t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+            for (int s4 = 0; s4 < 4; ++s4) {
+              t0 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 4 * s4 + lq], X[(4 * s4 + lq) * DLD + tj * 16 + lr], t0);
+              t1 = mfma_f64(A[(32 + ti * 16 + lr) * DLD + 16 + 4 * s4 + lq], X[(16 + 4 * s4 + lq) * DLD + tj * 16 + lr], t1);
+            }
           }
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
@@ -368,7 +375,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
     // step's factor phase, where they idle anyway (see there).
     if (VAR >= 1) {
       const int i = kb + 1 + wave;
-      if (i < 4) block16_update(A, i, kb + 1, o, lr, lq);
+      if (i < nl) block16_update(A, i, kb + 1, o, lr, lq);
     } else {
       int pidx = 0;
       for (int i = kb + 1; i < 4; ++i)
@@ -384,7 +391,7 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
   // What is left of the inverse doubling (VAR 1 did the pair (0,1) and T = L[32:64,0:32] X[0:32,0:32] inside the
   // loop, on waves that were idle): the pair (2,3), then X[32:64, 0:32] = -X[32:64, 32:64] * T.
   if (VAR >= 1 && wave > 0) hook(4, wave);  // waves 1..3 wait for wave 0's pair (2,3) here
-  if (VAR >= 1 ? wave == 0 : wave < 2) {
+  if ((VAR >= 1 ? wave == 0 : wave < 2) && (VAR == 0 || 3 < nl)) {
     const int a0 = (VAR >= 1 ? 1 : wave) * 32, c0 = a0 + 16;
     d4_t t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -410,14 +417,16 @@ __device__ __forceinline__ void diag_core(double *__restrict__ A, double *__rest
       for (int rr = 0; rr < 4; ++rr) T[(ti * 16 + lq + 4 * rr) * TLD + tj * 16 + lr] = t0[rr] + t1[rr];
       diag_barrier<LB>();
     }
-    d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+    if (VAR == 0 || 2 + ti < nl) {
+      d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      x0 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 32 + 4 * s4 + lq], T[(4 * s4 + lq) * TLD + tj * 16 + lr], x0);
-      x1 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 48 + 4 * s4 + lq], T[(16 + 4 * s4 + lq) * TLD + tj * 16 + lr], x1);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        x0 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 32 + 4 * s4 + lq], T[(4 * s4 + lq) * TLD + tj * 16 + lr], x0);
+        x1 = mfma_f64(-X[(32 + ti * 16 + lr) * DLD + 48 + 4 * s4 + lq], T[(16 + 4 * s4 + lq) * TLD + tj * 16 + lr], x1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = x0[rr] + x1[rr];
     }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) X[(32 + ti * 16 + lq + 4 * rr) * DLD + tj * 16 + lr] = x0[rr] + x1[rr];
   }
   diag_barrier<LB>();
 #undef B7_DIAG_STAMP
