@@ -32,7 +32,9 @@ class slice_sampler(object):
     def sample(cls, f, X0, opt, f_args=None):
         """samplers/slice.lua:51-89.  X0: 1 x xDim start; returns nSamples x xDim (each drawn from X0)."""
         rng = opt["rng"]
-        X0 = np.tile(np.atleast_2d(np.asarray(X0, dtype=np.float64)), (int(opt["nSamples"]), 1))
+        X0 = np.atleast_2d(np.asarray(X0, dtype=np.float64))
+        if int(opt["nSamples"]) != 1:             # (X0 is only read: the one-sample case needs no copy)
+            X0 = np.tile(X0, (int(opt["nSamples"]), 1))
         N, xDim = X0.shape
         samples = np.empty((N, xDim))
         if opt.get("gibbs"):                      # :58-75
